@@ -1,0 +1,128 @@
+/*
+ * nmpc.h — C ABI of the MI355X batched NMPC solver (libnmpc_hip.so).
+ *
+ * Drop-in boundary for the per-timestep solve of the reference scripts
+ *   AS = AllScripts/ of asalimil/Nonlinear-MPC-for-collision-free-and-deadlock-free-
+ *        navigation-of-multiple-nonholonomic-mobile-robots
+ *   C6 = AS/centralized_six_robots_implementation.py
+ *
+ * The reference has no FFI of its own: the boundary it exposes is the CasADi solver
+ * object call plus shift():
+ *     solver = nlpsol('solver','ipopt', nlp_prob, opts)          C6:345-346
+ *     sol    = solver(x0=,p=,lbx=,ubx=,lbg=,ubg=)                C6:432
+ *     t0, u0 = shift(T, t0, u)                                   C6:160-169,450
+ * Each entry point below names the block it replaces.  All buffers are caller-owned
+ * DEVICE pointers (fp64 / int32), row-major with the batch index leading.  No global
+ * state; every call is ordered on the hipStream_t passed as `void *stream` (NULL = the
+ * default stream).  Return value: 0 on success, negative NMPC_E_* on argument / HIP
+ * errors.  Non-convergence is NOT an error (the reference never reads solver.stats());
+ * it is reported per instance in `status`.
+ */
+#ifndef NMPC_H_
+#define NMPC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMPC_MAX_ROBOTS 10
+#define NMPC_MAX_OBSTACLES 8
+
+/* per-instance solve status */
+#define NMPC_STATUS_CONVERGED 0      /* scaled KKT error <= tol                                  */
+#define NMPC_STATUS_MAX_ITER 1       /* iteration limit hit; last iterate returned               */
+#define NMPC_STATUS_NUMERIC 2        /* inertia correction exhausted / non-finite step           */
+#define NMPC_STATUS_INFEASIBLE_X0 3  /* a stage-0 pair/obstacle row is violated by the pinned x0 */
+
+/* return codes */
+#define NMPC_OK 0
+#define NMPC_E_ARG (-1)
+#define NMPC_E_UNSUPPORTED (-2)
+#define NMPC_E_HIP (-3)
+#define NMPC_E_NOMEM (-4)
+
+/*
+ * Every literal of one reference script (C6:197-205 T,N,m,dmin,v_max,omega_max;
+ * C6:252-266 Q,R; C6:349-352 bounds; obstacle literals
+ * AS/third_scenario_mpc_obstacle_avoidance.py:58,97-119,175-177).
+ */
+typedef struct nmpc_config {
+    int32_t m;              /* robots, 1..NMPC_MAX_ROBOTS                                       */
+    int32_t N;              /* horizon                                                          */
+    int32_t n_obs;          /* static circular obstacles, 0..NMPC_MAX_OBSTACLES                 */
+    int32_t pad_rows;       /* 1: initial g block carries M constant rows (C6:278); 0: it does not */
+    double T;               /* sample time                                                      */
+    double dmin;            /* pair rows bounded below by dmin^2 (C6:349)                       */
+    double q[3];            /* Q diagonal per robot                                             */
+    double r[2];            /* R diagonal per robot                                             */
+    double v_max, w_max;    /* |v| <= v_max, |omega| <= w_max                                   */
+    double xy_max;          /* |x|,|y| <= xy_max (10 in every script)                           */
+    double th_max;          /* |theta| <= th_max; +inf = unbounded (multi-robot scripts)        */
+    double rob_dim, margin; /* obstacle rows: sqrt(.) - rob_dim - obs_r >= margin               */
+    double pad_value;       /* 3.5 (C6:278)                                                     */
+    double obs[3 * NMPC_MAX_OBSTACLES]; /* (ox, oy, obs_r) per obstacle                         */
+    /* solver options: the 'ipopt' dict of C6:345 plus IPOPT defaults that matter */
+    double tol;             /* 1e-8 (acceptable_tol of C6:345 == IPOPT tol)                     */
+    double mu_init;         /* 0.1 (IPOPT default)                                              */
+    int32_t max_iter;       /* reference: 2000                                                  */
+    int32_t reserved;
+} nmpc_config_t;
+
+typedef struct nmpc_handle nmpc_handle_t;
+
+/* sizes implied by a config */
+int32_t nmpc_n_var(const nmpc_config_t *cfg); /* n_x (N+1) + n_u N                    (C6:339) */
+int32_t nmpc_n_g(const nmpc_config_t *cfg);   /* rows of g in the reference's order   (C6:278,326-331) */
+int32_t nmpc_n_p(const nmpc_config_t *cfg);   /* 2 n_x                                (C6:241) */
+
+/* fills *cfg with the defaults above and the Q/R/bounds literals shared by all scripts */
+void nmpc_config_default(nmpc_config_t *cfg, int32_t m, int32_t N);
+
+/*
+ * Replaces nlpsol('solver','ipopt',nlp_prob,opts) (C6:342-346): validates the config and
+ * allocates a device workspace for up to max_batch instances.
+ */
+int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t **out);
+int32_t nmpc_destroy(nmpc_handle_t *h);
+
+/* bytes of device workspace held by the handle */
+int64_t nmpc_workspace_bytes(const nmpc_handle_t *h);
+
+/*
+ * Replaces sol = solver(x0=,p=,lbx=,ubx=,lbg=,ubg=) (C6:432) for B independent swarms.
+ *   p      [B][2 n_x]   parameters [x0; xs]                       (C6:419)
+ *   w0     [B][n_var]   initial guess [X_0..X_N; U_0..U_{N-1}]     (C6:423)
+ *   w_out  [B][n_var]   sol['x']                                   (C6:436,440)
+ *   obj    [B]          sol['f']           (may be NULL)
+ *   status [B] iters[B] kkt[B]             (may be NULL)
+ * Bounds are those of the config (the scripts never change them between calls).
+ */
+int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out,
+                         double *obj, int32_t *status, int32_t *iters, double *kkt, void *stream);
+
+/*
+ * Evaluates the NLP functions in the reference's layout at w: f (C6:314) and
+ * g [B][n_g] (C6:278,318-331).  Backs sol['f'] / sol['g'] of the host wrapper.
+ */
+int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g,
+                        void *stream);
+
+/*
+ * Replaces shift() and the warm-start row shuffle (C6:160-169,450,460-465):
+ *   U rows: drop first, duplicate last;  X rows: [X_1..X_N; X_{N-1}].
+ * x0_next [B][n_x] may be NULL; when given it is written as the plant step
+ *   x0 + T f(x0, u_0) of AS/casadi_test.py:17-26 (x0 read from p_in[:, :n_x]).
+ * w_in and w_next must not alias.
+ */
+int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const double *w_in, double *w_next,
+                         double *x0_next, void *stream);
+
+/* library / kernel identification string (build flags, arch) */
+const char *nmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMPC_H_ */

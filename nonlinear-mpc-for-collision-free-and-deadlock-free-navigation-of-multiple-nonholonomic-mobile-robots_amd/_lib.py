@@ -1,0 +1,62 @@
+"""ctypes binding of the C ABI in include/nmpc.h (libnmpc_hip.so).  No CPU fallback exists:
+if the library is missing or no GPU is visible the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libnmpc_hip.so")
+
+NMPC_MAX_ROBOTS = 10
+NMPC_MAX_OBSTACLES = 8
+
+STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Error_In_Step_Computation",
+                3: "Infeasible_Problem_Detected"}
+ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMPC_E_NOMEM"}
+
+EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_destroy",
+           "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_version"]
+
+
+class CConfig(C.Structure):
+    """nmpc_config_t"""
+    _fields_ = [("m", C.c_int32), ("N", C.c_int32), ("n_obs", C.c_int32), ("pad_rows", C.c_int32),
+                ("T", C.c_double), ("dmin", C.c_double), ("q", C.c_double * 3), ("r", C.c_double * 2),
+                ("v_max", C.c_double), ("w_max", C.c_double), ("xy_max", C.c_double), ("th_max", C.c_double),
+                ("rob_dim", C.c_double), ("margin", C.c_double), ("pad_value", C.c_double),
+                ("obs", C.c_double * (3 * NMPC_MAX_OBSTACLES)), ("tol", C.c_double), ("mu_init", C.c_double),
+                ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libnmpc_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(f"{SO_PATH} is missing: build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    cp = C.POINTER(CConfig)
+    for f in ("nmpc_n_var", "nmpc_n_g", "nmpc_n_p"):
+        getattr(L, f).argtypes = [cp]; getattr(L, f).restype = i32
+    L.nmpc_config_default.argtypes = [cp, i32, i32]; L.nmpc_config_default.restype = None
+    L.nmpc_create.argtypes = [cp, i32, C.POINTER(vp)]; L.nmpc_create.restype = i32
+    L.nmpc_destroy.argtypes = [vp]; L.nmpc_destroy.restype = i32
+    L.nmpc_workspace_bytes.argtypes = [vp]; L.nmpc_workspace_bytes.restype = C.c_int64
+    L.nmpc_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch.restype = i32
+    L.nmpc_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_eval_batch.restype = i32
+    L.nmpc_shift_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_shift_batch.restype = i32
+    L.nmpc_version.argtypes = []; L.nmpc_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

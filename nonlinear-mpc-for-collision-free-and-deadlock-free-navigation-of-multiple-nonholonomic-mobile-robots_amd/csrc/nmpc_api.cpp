@@ -1,0 +1,133 @@
+// nmpc_api.cpp — the C ABI of include/nmpc.h on top of the gfx950 kernels.
+//
+// There is deliberately no CPU fallback in this library: every entry point either runs the
+// HIP kernels or returns an error code.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "nmpc_device.h"
+
+struct nmpc_handle {
+    nmpc_config_t cfg;
+    nmpc::KParams P;
+    int32_t max_batch;
+    double *ws;          // device workspace: max_batch * stride doubles
+    int64_t ws_bytes;
+};
+
+static bool m_supported(int m) { return (m >= 1 && m <= 6) || m == 8 || m == 10; }
+
+extern "C" {
+
+int32_t nmpc_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * c->m * c->N; }
+int32_t nmpc_n_p(const nmpc_config_t *c) { return 6 * c->m; }
+int32_t nmpc_n_g(const nmpc_config_t *c)
+{
+    int M = c->m * (c->m - 1) / 2;
+    return 3 * c->m + (c->pad_rows ? M : 0) + (3 * c->m + M + c->m * c->n_obs) * c->N;
+}
+
+void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
+{
+    memset(c, 0, sizeof(*c));
+    c->m = m; c->N = N; c->n_obs = 0; c->pad_rows = m > 1;
+    c->T = 0.05; c->dmin = 0.15;
+    c->q[0] = 1.0; c->q[1] = 5.0; c->q[2] = 0.1;
+    c->r[0] = 0.5; c->r[1] = 0.05;
+    c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
+    c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
+    c->tol = 1e-8; c->mu_init = 0.1; c->max_iter = 2000;
+}
+
+static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
+{
+    memset(P, 0, sizeof(*P));
+    const int m = c->m, N = c->N, nx = 3 * m, nu = 2 * m, M = m * (m - 1) / 2, K = c->n_obs;
+    P->m = m; P->N = N; P->K = K;
+    P->thb = isfinite(c->th_max) ? 1 : 0;
+    P->nxb = m * (P->thb ? 3 : 2);
+    P->nh = 2 * nu + 2 * P->nxb + M + m * K;
+    P->o_ul = 0; P->o_uu = nu; P->o_xl = 2 * nu; P->o_xu = P->o_xl + P->nxb; P->o_pr = P->o_xu + P->nxb; P->o_ob = P->o_pr + M;
+    P->n_ineq = N * 2 * nu + N * 2 * P->nxb + (N - 1) * (M + m * K);
+    P->nvar = nmpc_n_var(c); P->ng = nmpc_n_g(c);
+    P->rows0 = nx + (c->pad_rows ? M : 0); P->rowsk = nx + M + m * K;
+    P->pad_rows = c->pad_rows; P->pad_value = c->pad_value; P->max_iter = c->max_iter;
+    P->T = c->T; P->dmin2 = c->dmin * c->dmin; P->vmax = c->v_max; P->wmax = c->w_max; P->xymax = c->xy_max; P->thmax = c->th_max;
+    P->robdim = c->rob_dim; P->margin = c->margin; P->tol = c->tol; P->mu_init = c->mu_init;
+    for (int d = 0; d < 3; d++) P->q[d] = c->q[d];
+    for (int d = 0; d < 2; d++) P->r[d] = c->r[d];
+    memcpy(P->obs, c->obs, sizeof(P->obs));
+    // workspace carve-up; every array starts on a 128-byte boundary
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t at = o; o += (n + 15) / 16 * 16; return (int32_t)at; };
+    const int64_t nX = (int64_t)(N + 1) * nx, nU = (int64_t)N * nu, nH = (int64_t)(N + 1) * P->nh;
+    P->oX = take(nX); P->oU = take(nU); P->oLAM = take(nX); P->oS = take(nH); P->oZ = take(nH);
+    P->oDX = take(nX); P->oDU = take(nU); P->oLAMN = take(nX); P->oDS = take(nH); P->oDZ = take(nH);
+    P->oSN = take((int64_t)N * m); P->oCS = take((int64_t)N * m); P->oC = take(nX); P->oH = take(nH); P->oGX = take(nX);
+    P->oHUU = take(nU); P->oGU = take(nU); P->oHVT = take((int64_t)N * m); P->oHTT = take((int64_t)N * m);
+    P->oKG = take((int64_t)N * nu * nx); P->oKFF = take(nU);
+    P->stride = o;
+    return 0;
+}
+
+int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t **out)
+{
+    if (!cfg || !out || max_batch < 1) return NMPC_E_ARG;
+    if (cfg->N < 2 || cfg->N > 4096 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
+    if (!(cfg->T > 0.0) || !(cfg->v_max > 0.0) || !(cfg->w_max > 0.0) || !(cfg->xy_max > 0.0) || !(cfg->th_max > 0.0)) return NMPC_E_ARG;
+    if (!(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0) return NMPC_E_ARG;
+    if (!m_supported(cfg->m)) return NMPC_E_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;   // fail loudly: no CPU path exists
+    nmpc_handle *h = (nmpc_handle *)calloc(1, sizeof(nmpc_handle));
+    if (!h) return NMPC_E_NOMEM;
+    h->cfg = *cfg;
+    fill_params(cfg, &h->P);
+    h->max_batch = max_batch;
+    h->ws_bytes = (int64_t)sizeof(double) * h->P.stride * max_batch;
+    if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
+    *out = h;
+    return NMPC_OK;
+}
+
+int32_t nmpc_destroy(nmpc_handle_t *h)
+{
+    if (!h) return NMPC_E_ARG;
+    if (h->ws) (void)hipFree(h->ws);
+    free(h);
+    return NMPC_OK;
+}
+
+int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 0; }
+
+int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                         int32_t *iters, double *kkt, void *stream)
+{
+    if (!h || !p || !w0 || !w_out || B < 0 || B > h->max_batch) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    hipError_t e = nmpc::launch_solve(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream);
+    return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream)
+{
+    if (!h || !p || !w || B < 0) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    hipError_t e = nmpc::launch_eval(h->P, h->cfg.m, B, p, w, f, g, (hipStream_t)stream);
+    return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const double *w_in, double *w_next, double *x0_next, void *stream)
+{
+    if (!h || !w_in || !w_next || w_in == w_next || B < 0) return NMPC_E_ARG;
+    if (x0_next && !p_in) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, (hipStream_t)stream);
+    return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+const char *nmpc_version(void) { return "nmpc_hip 0.1 (gfx950, fp64, one workgroup per instance)"; }
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// nmpc_device.h — kernel parameter block shared by nmpc_kernels.hip and nmpc_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nmpc.h"
+
+namespace nmpc {
+
+// Passed by value to every kernel (lands in SGPRs / the kernarg segment).
+struct KParams {
+    int32_t m, N, K, thb, nxb, nh, n_ineq, nvar, ng, rows0, rowsk, pad_rows, max_iter;
+    int32_t o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;     // inequality slot offsets inside one stage block
+    double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin, pad_value, tol, mu_init;
+    double q[3], r[2];
+    double obs[3 * NMPC_MAX_OBSTACLES];
+    // per-instance workspace carve-up, in doubles
+    int64_t stride;
+    int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;
+};
+
+hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                        int32_t *iters, double *kkt, double *ws, hipStream_t st);
+hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
+hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);
+
+}  // namespace nmpc

@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference's call surface for the per-step solve.
+
+    solver = nlpsol('solver', 'ipopt', cfg, opts)                 # C6:345-346
+    sol    = solver(x0=, p=, lbx=, ubx=, lbg=, ubg=)              # C6:432 ; sol['x'] (n_var x 1)
+    t0, u0 = shift(T, t0, u)                                      # C6:160-169,450
+
+(C6 = AllScripts/centralized_six_robots_implementation.py.)  The batched overloads take a
+leading batch dimension and keep everything on the GPU as torch tensors.  torch is used for
+device memory and streams only; all arithmetic happens in libnmpc_hip.so through its C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .problem import ProblemConfig
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the NMPC solve has no CPU fallback")
+    return torch
+
+
+def shift(T, t0, u):
+    """C6:160-169: t0 += T ; u0 = [u[1:]; u[-1]] (drop first row, duplicate last)."""
+    u = np.asarray(u)
+    u0 = np.concatenate((u[1:u.shape[0], 0:], u[u.shape[0] - 1:u.shape[0], 0:]), axis=0)
+    return t0 + T, u0
+
+
+def shift_states(X, N=None):
+    """C6:465: X0 = [X[1:]; X[N-1]] — the appended row is row N-1 of the (N+1)-row array."""
+    X = np.asarray(X)
+    N = X.shape[0] - 1 if N is None else N
+    return np.concatenate((X[1:], X[N - 1:N]), axis=0)
+
+
+def cold_start(cfg: ProblemConfig, x0) -> np.ndarray:
+    """C6:398-400,423: X0 = repmat(x0), u0 = 0, packed [vec(X); vec(U)]."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+    return np.concatenate([np.tile(x0, cfg.N + 1), np.zeros(cfg.nu * cfg.N)])
+
+
+class NmpcSolver:
+    """The object nlpsol() returns.  Owns a device workspace sized for `max_batch` instances."""
+
+    def __init__(self, cfg: ProblemConfig, max_batch: int = 1, device: Optional[int] = None):
+        self.cfg = cfg
+        self.torch = _torch()
+        self.lib = _lib.load()
+        self.device = self.torch.device("cuda", self.torch.cuda.current_device() if device is None else device)
+        self._ccfg = cfg.to_c()
+        self._h = C.c_void_p()
+        self.max_batch = int(max_batch)
+        with self.torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_create(C.byref(self._ccfg), self.max_batch, C.byref(self._h)), "nmpc_create")
+        self.n_var, self.n_g, self.n_p = cfg.n_var, cfg.n_g, cfg.n_p
+        assert self.n_var == self.lib.nmpc_n_var(C.byref(self._ccfg)) and self.n_g == self.lib.nmpc_n_g(C.byref(self._ccfg))
+        self._stats: Dict = {}
+        self._bounds = cfg.bounds()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.nmpc_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.nmpc_workspace_bytes(self._h))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, shape):
+        t = self.torch.as_tensor(a, dtype=self.torch.float64, device=self.device).reshape(shape).contiguous()
+        return t
+
+    # ---- batched device API -----------------------------------------------------------------
+    def solve_batch(self, p, w0, want_fg: bool = False):
+        """p [B, 2 n_x], w0 [B, n_var] (torch cuda / numpy) -> dict of torch cuda tensors."""
+        torch = self.torch
+        p = self._dev(p, (-1, self.n_p)); B = p.shape[0]
+        w0 = self._dev(w0, (B, self.n_var))
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        w = torch.empty((B, self.n_var), dtype=torch.float64, device=self.device)
+        obj = torch.empty(B, dtype=torch.float64, device=self.device)
+        kkt = torch.empty(B, dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        iters = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_solve_batch(self._h, B, p.data_ptr(), w0.data_ptr(), w.data_ptr(), obj.data_ptr(),
+                                                 status.data_ptr(), iters.data_ptr(), kkt.data_ptr(), self._stream()), "nmpc_solve_batch")
+        out = dict(x=w, f=obj, status=status, iters=iters, kkt=kkt)
+        if want_fg:
+            f, g = self.eval_batch(p, w)
+            out["f"], out["g"] = f, g
+        return out
+
+    def eval_batch(self, p, w):
+        torch = self.torch
+        p = self._dev(p, (-1, self.n_p)); B = p.shape[0]
+        w = self._dev(w, (B, self.n_var))
+        f = torch.empty(B, dtype=torch.float64, device=self.device)
+        g = torch.empty((B, self.n_g), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_eval_batch(self._h, B, p.data_ptr(), w.data_ptr(), f.data_ptr(), g.data_ptr(), self._stream()), "nmpc_eval_batch")
+        return f, g
+
+    def shift_batch(self, p, w, plant: bool = True):
+        """device warm-start shift (C6:160-169,460-465) and, if plant, x0 + T f(x0,u0) (casadi_test.py:17-26)."""
+        torch = self.torch
+        p = self._dev(p, (-1, self.n_p)); B = p.shape[0]
+        w = self._dev(w, (B, self.n_var))
+        wn = torch.empty_like(w)
+        x0n = torch.empty((B, self.cfg.nx), dtype=torch.float64, device=self.device) if plant else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_shift_batch(self._h, B, p.data_ptr(), w.data_ptr(), wn.data_ptr(),
+                                                 x0n.data_ptr() if plant else None, self._stream()), "nmpc_shift_batch")
+        return wn, x0n
+
+    # ---- the reference's single-instance keyword call (C6:432) ----------------------------------
+    def __call__(self, x0=None, p=None, lbx=None, ubx=None, lbg=None, ubg=None, **kw):
+        if kw:
+            raise TypeError(f"unexpected arguments {sorted(kw)}")
+        if p is None or x0 is None:
+            raise ValueError("x0 and p are required")
+        p = np.asarray(p, dtype=np.float64).reshape(-1)
+        w0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+        if p.size != self.n_p:
+            raise ValueError(f"p has {p.size} entries, expected {self.n_p}")
+        if w0.size != self.n_var:
+            raise ValueError(f"x0 has {w0.size} entries, expected {self.n_var}")
+        # bounds are structural here: accept (n,1)/(1,n)/flat, and insist they are the configured ones
+        for name, given, want in (("lbx", lbx, self._bounds[0]), ("ubx", ubx, self._bounds[1]),
+                                  ("lbg", lbg, self._bounds[2]), ("ubg", ubg, self._bounds[3])):
+            if given is None:
+                continue
+            g = np.asarray(given, dtype=np.float64).reshape(-1)
+            if g.size != want.size:
+                raise ValueError(f"{name} has {g.size} entries, expected {want.size}")
+            if not np.array_equal(g, want):
+                raise ValueError(f"{name} differs from the bounds of the configured problem; build a new config instead")
+        r = self.solve_batch(p[None, :], w0[None, :], want_fg=True)
+        self.torch.cuda.synchronize(self.device)
+        st = int(r["status"][0])
+        self._stats = dict(return_status=_lib.STATUS_NAMES.get(st, str(st)), success=(st == 0), iter_count=int(r["iters"][0]),
+                           kkt_error=float(r["kkt"][0]), status_code=st)
+        return {"x": r["x"][0].cpu().numpy().reshape(-1, 1), "f": float(r["f"][0]), "g": r["g"][0].cpu().numpy().reshape(-1, 1)}
+
+    def stats(self) -> Dict:
+        """CasADi's solver.stats(); the reference never reads it, non-convergence is reported here only."""
+        return dict(self._stats)
+
+
+def nlpsol(name: str, plugin: str, problem, opts: Optional[dict] = None, max_batch: int = 1) -> NmpcSolver:
+    """Drop-in for casadi.nlpsol(name,'ipopt',nlp_prob,opts) (C6:345-346) with `problem` a ProblemConfig.
+
+    Honoured keys of opts['ipopt']: max_iter, tol / acceptable_tol, mu_init; print_* are accepted and ignored."""
+    if plugin != "ipopt":
+        raise ValueError("only the 'ipopt' call surface of the reference is mirrored")
+    if not isinstance(problem, ProblemConfig):
+        raise TypeError("problem must be a ProblemConfig (the symbolic CasADi graph is replaced by its parameters)")
+    ip = dict((opts or {}).get("ipopt", {}))
+    cfg = ProblemConfig(**{**problem.__dict__})
+    if "max_iter" in ip: cfg.max_iter = int(ip["max_iter"])
+    if "tol" in ip: cfg.tol = float(ip["tol"])
+    elif "acceptable_tol" in ip: cfg.tol = float(ip["acceptable_tol"])
+    if "mu_init" in ip: cfg.mu_init = float(ip["mu_init"])
+    return NmpcSolver(cfg, max_batch=max_batch)

@@ -1,0 +1,730 @@
+/*
+ * nmpc_oracle.c — TEST INFRASTRUCTURE.  CPU fp64 restatement of the reference's per-step
+ * NMPC solve.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's library; the product (libnmpc_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED against CasADi/IPOPT: the reference's arithmetic lives in the
+ * un-vendored, unpinned third-party packages `casadi` and IPOPT (call sites
+ * C6:15,207-346,432), neither installed here, and the reference holds no tests or golden
+ * vectors.  This file is pinned instead by (a) the solver-independent known answers of
+ * SURVEY.md §8c items 1-5 via oracle/nlp_ref.py, (b) scipy-SLSQP golden triples in
+ * tests/golden/ ("scipy-SLSQP oracle, not CasADi/IPOPT").
+ *
+ * What is restated (C6 = AllScripts/centralized_six_robots_implementation.py):
+ *   NLP:    unicycle rhs C6:207-237; Euler defect C6:318-323; stage cost C6:314 with
+ *           Q,R of C6:252-266; pair rows C6:288-306; initial block C6:273-278; packing
+ *           C6:339; bounds C6:349-352; obstacle rows
+ *           AllScripts/third_scenario_mpc_obstacle_avoidance.py:145-150,175-177.
+ *   solve:  C6:345-346,432 — nlpsol('ipopt').  IPOPT is absent, so its published
+ *           algorithm (Waechter & Biegler, Math. Program. 106, 2006) is restated:
+ *           slack/barrier reformulation, monotone mu update (their eq. 7 with
+ *           kappa_mu=0.2, theta_mu=1.5, kappa_eps=10), fraction-to-boundary (eq. 8, 15),
+ *           dual safeguard (eq. 16), scaled optimality error (eq. 5-6, s_max=100),
+ *           inertia correction schedule (alg. IC), bound_push=1e-2; the linear system
+ *           is solved by a Riccati sweep over the stages (block elimination of the same
+ *           KKT matrix) and the line search is an l1-merit backtracking search instead
+ *           of IPOPT's filter.  Parity is therefore at the KKT point, not on iterates.
+ *   shift:  C6:160-169,460-465; plant step AllScripts/casadi_test.py:17-26.
+ *
+ * Plain scalar C99, one instance at a time; the batch driver runs instances in
+ * parallel with OpenMP (one instance per thread).
+ */
+#include "../include/nmpc.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NXM (3 * NMPC_MAX_ROBOTS)
+#define NUM_ (2 * NMPC_MAX_ROBOTS)
+
+typedef struct {
+    int m, N, K, nx, nu, M, nxb, nh, thb;
+    int o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;
+    double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin;
+    double qd[NXM], rd[NUM_], lbu[NUM_], ubu[NUM_], bxs[NXM];
+    int pi[NMPC_MAX_ROBOTS * (NMPC_MAX_ROBOTS - 1) / 2], pj[NMPC_MAX_ROBOTS * (NMPC_MAX_ROBOTS - 1) / 2];
+    int bidx[NXM]; /* bounded-state slot -> state index */
+    double obs[3 * NMPC_MAX_OBSTACLES];
+    double tol, mu_init;
+    int max_iter;
+    /* iterate + step */
+    double *X, *U, *lam, *S, *Z, *dX, *dU, *lamn, *dS, *dZ;
+    double *Xt, *Ut, *St;
+    double *sn, *cs, *C, *H, *Ht, *Ct, *snt, *cst;
+    double *Hxx, *gx, *huu, *gu, *hvt, *Kg, *kff;
+} ws_t;
+
+int32_t nmpc_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * c->m * c->N; }
+int32_t nmpc_n_p(const nmpc_config_t *c) { return 6 * c->m; }
+int32_t nmpc_n_g(const nmpc_config_t *c)
+{
+    int M = c->m * (c->m - 1) / 2;
+    return 3 * c->m + (c->pad_rows ? M : 0) + (3 * c->m + M + c->m * c->n_obs) * c->N;
+}
+
+void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
+{
+    memset(c, 0, sizeof(*c));
+    c->m = m; c->N = N; c->n_obs = 0; c->pad_rows = m > 1;
+    c->T = 0.05; c->dmin = 0.15;
+    c->q[0] = 1.0; c->q[1] = 5.0; c->q[2] = 0.1;
+    c->r[0] = 0.5; c->r[1] = 0.05;
+    c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
+    c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
+    c->tol = 1e-8; c->mu_init = 0.1; c->max_iter = 2000;
+}
+
+static ws_t *ws_new(const nmpc_config_t *c)
+{
+    ws_t *w = (ws_t *)calloc(1, sizeof(ws_t));
+    int m = c->m, N = c->N;
+    w->m = m; w->N = N; w->K = c->n_obs; w->nx = 3 * m; w->nu = 2 * m; w->M = m * (m - 1) / 2;
+    w->thb = isfinite(c->th_max) ? 1 : 0;
+    w->nxb = m * (w->thb ? 3 : 2);
+    w->nh = 2 * w->nu + 2 * w->nxb + w->M + m * w->K;
+    w->o_ul = 0; w->o_uu = w->nu; w->o_xl = 2 * w->nu; w->o_xu = w->o_xl + w->nxb;
+    w->o_pr = w->o_xu + w->nxb; w->o_ob = w->o_pr + w->M;
+    w->T = c->T; w->dmin2 = c->dmin * c->dmin; w->vmax = c->v_max; w->wmax = c->w_max;
+    w->xymax = c->xy_max; w->thmax = c->th_max; w->robdim = c->rob_dim; w->margin = c->margin;
+    w->tol = c->tol; w->mu_init = c->mu_init; w->max_iter = c->max_iter;
+    memcpy(w->obs, c->obs, sizeof(w->obs));
+    for (int i = 0; i < m; i++) {
+        for (int d = 0; d < 3; d++) w->qd[3 * i + d] = c->q[d];
+        for (int d = 0; d < 2; d++) w->rd[2 * i + d] = c->r[d];
+        w->lbu[2 * i] = -c->v_max; w->ubu[2 * i] = c->v_max;
+        w->lbu[2 * i + 1] = -c->w_max; w->ubu[2 * i + 1] = c->w_max;
+    }
+    int np = 0;
+    for (int i = 0; i < m; i++) for (int j = i + 1; j < m; j++) { w->pi[np] = i; w->pj[np] = j; np++; }
+    for (int s = 0; s < w->nxb; s++) {
+        if (w->thb) { w->bidx[s] = s; w->bxs[s] = (s % 3 == 2) ? c->th_max : c->xy_max; }
+        else { w->bidx[s] = 3 * (s / 2) + (s % 2); w->bxs[s] = c->xy_max; }
+    }
+    size_t nX = (size_t)(N + 1) * w->nx, nU = (size_t)N * w->nu, nH = (size_t)(N + 1) * w->nh;
+#define AL(p, n) w->p = (double *)calloc((n), sizeof(double))
+    AL(X, nX); AL(U, nU); AL(lam, nX); AL(S, nH); AL(Z, nH); AL(dX, nX); AL(dU, nU); AL(lamn, nX); AL(dS, nH); AL(dZ, nH);
+    AL(Xt, nX); AL(Ut, nU); AL(St, nH);
+    AL(sn, (size_t)N * m); AL(cs, (size_t)N * m); AL(snt, (size_t)N * m); AL(cst, (size_t)N * m);
+    AL(C, nX); AL(Ct, nX); AL(H, nH); AL(Ht, nH);
+    AL(Hxx, (size_t)(N + 1) * w->nx * w->nx); AL(gx, nX); AL(huu, nU); AL(gu, nU); AL(hvt, (size_t)N * m);
+    AL(Kg, (size_t)N * w->nu * w->nx); AL(kff, nU);
+#undef AL
+    return w;
+}
+
+static void ws_free(ws_t *w)
+{
+    double **ps[] = {&w->X, &w->U, &w->lam, &w->S, &w->Z, &w->dX, &w->dU, &w->lamn, &w->dS, &w->dZ, &w->Xt, &w->Ut, &w->St,
+                     &w->sn, &w->cs, &w->snt, &w->cst, &w->C, &w->Ct, &w->H, &w->Ht, &w->Hxx, &w->gx, &w->huu, &w->gu,
+                     &w->hvt, &w->Kg, &w->kff};
+    for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); i++) free(*ps[i]);
+    free(w);
+}
+
+/* which inequality slots exist at stage k: u rows k<N; x-bound rows k>=1; pair/obstacle rows 1<=k<=N-1 */
+static inline int slot_active(const ws_t *w, int k, int s)
+{
+    if (s < w->o_xl) return k < w->N;
+    if (s < w->o_pr) return k >= 1;
+    return k >= 1 && k <= w->N - 1;
+}
+
+/* inequality values h_s(x_k,u_k) >= 0 for all active slots of stage k */
+static void stage_h(const ws_t *w, int k, const double *x, const double *u, double *h)
+{
+    for (int s = 0; s < w->nh; s++) h[s] = 1.0;
+    if (k < w->N)
+        for (int c = 0; c < w->nu; c++) { h[w->o_ul + c] = u[c] - w->lbu[c]; h[w->o_uu + c] = w->ubu[c] - u[c]; }
+    if (k >= 1)
+        for (int s = 0; s < w->nxb; s++) { double v = x[w->bidx[s]]; h[w->o_xl + s] = v + w->bxs[s]; h[w->o_xu + s] = w->bxs[s] - v; }
+    if (k >= 1 && k <= w->N - 1) {
+        for (int pq = 0; pq < w->M; pq++) {
+            int i = w->pi[pq], j = w->pj[pq];
+            double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
+            h[w->o_pr + pq] = dx * dx + dy * dy - w->dmin2;
+        }
+        for (int i = 0; i < w->m; i++)
+            for (int o = 0; o < w->K; o++) {
+                double dx = x[3 * i] - w->obs[3 * o], dy = x[3 * i + 1] - w->obs[3 * o + 1];
+                h[w->o_ob + i * w->K + o] = sqrt(dx * dx + dy * dy) - w->robdim - w->obs[3 * o + 2] - w->margin;
+            }
+    }
+}
+
+/* out += Jx_k^T v  (x-rows of stage k; v indexed by slot) */
+static void jxT_apply(const ws_t *w, int k, const double *x, const double *v, double *out)
+{
+    if (k >= 1)
+        for (int s = 0; s < w->nxb; s++) out[w->bidx[s]] += v[w->o_xl + s] - v[w->o_xu + s];
+    if (k >= 1 && k <= w->N - 1) {
+        for (int pq = 0; pq < w->M; pq++) {
+            int i = w->pi[pq], j = w->pj[pq];
+            double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], z = v[w->o_pr + pq];
+            out[3 * i] += 2 * dx * z; out[3 * i + 1] += 2 * dy * z; out[3 * j] -= 2 * dx * z; out[3 * j + 1] -= 2 * dy * z;
+        }
+        for (int i = 0; i < w->m; i++)
+            for (int o = 0; o < w->K; o++) {
+                double dx = x[3 * i] - w->obs[3 * o], dy = x[3 * i + 1] - w->obs[3 * o + 1];
+                double rr = sqrt(dx * dx + dy * dy), z = v[w->o_ob + i * w->K + o];
+                out[3 * i] += dx / rr * z; out[3 * i + 1] += dy / rr * z;
+            }
+    }
+}
+
+/* out[slot] = (Jx_k d)[slot] for x-rows, (Ju_k du)[slot] for u-rows */
+static void j_apply(const ws_t *w, int k, const double *x, const double *dx_, const double *du, double *out)
+{
+    for (int s = 0; s < w->nh; s++) out[s] = 0.0;
+    if (k < w->N)
+        for (int c = 0; c < w->nu; c++) { out[w->o_ul + c] = du[c]; out[w->o_uu + c] = -du[c]; }
+    if (k >= 1)
+        for (int s = 0; s < w->nxb; s++) { double v = dx_[w->bidx[s]]; out[w->o_xl + s] = v; out[w->o_xu + s] = -v; }
+    if (k >= 1 && k <= w->N - 1) {
+        for (int pq = 0; pq < w->M; pq++) {
+            int i = w->pi[pq], j = w->pj[pq];
+            double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
+            out[w->o_pr + pq] = 2 * dx * (dx_[3 * i] - dx_[3 * j]) + 2 * dy * (dx_[3 * i + 1] - dx_[3 * j + 1]);
+        }
+        for (int i = 0; i < w->m; i++)
+            for (int o = 0; o < w->K; o++) {
+                double dx = x[3 * i] - w->obs[3 * o], dy = x[3 * i + 1] - w->obs[3 * o + 1];
+                double rr = sqrt(dx * dx + dy * dy);
+                out[w->o_ob + i * w->K + o] = (dx * dx_[3 * i] + dy * dx_[3 * i + 1]) / rr;
+            }
+    }
+}
+
+/* defects, inequality values, trig cache and objective at (X,U) */
+static double eval_point(const ws_t *w, const double *xs, const double *X, const double *U, double *sn, double *cs, double *C,
+                         double *H)
+{
+    int nx = w->nx, nu = w->nu, N = w->N, m = w->m;
+    double f = 0.0;
+    for (int k = 0; k < N; k++) {
+        const double *x = X + (size_t)k * nx, *xn = x + nx, *u = U + (size_t)k * nu;
+        for (int i = 0; i < m; i++) {
+            double s = sin(x[3 * i + 2]), c = cos(x[3 * i + 2]), v = u[2 * i], om = u[2 * i + 1];
+            sn[k * m + i] = s; cs[k * m + i] = c;
+            C[k * nx + 3 * i] = xn[3 * i] - (x[3 * i] + w->T * v * c);
+            C[k * nx + 3 * i + 1] = xn[3 * i + 1] - (x[3 * i + 1] + w->T * v * s);
+            C[k * nx + 3 * i + 2] = xn[3 * i + 2] - (x[3 * i + 2] + w->T * om);
+        }
+        for (int c = 0; c < nx; c++) { double e = x[c] - xs[c]; f += w->qd[c] * e * e; }
+        for (int c = 0; c < nu; c++) f += w->rd[c] * u[c] * u[c];
+    }
+    for (int k = 0; k <= N; k++) stage_h(w, k, X + (size_t)k * nx, k < N ? U + (size_t)k * nu : NULL, H + (size_t)k * w->nh);
+    return f;
+}
+
+static double barrier_and_infeas(const ws_t *w, double f, const double *C, const double *H, const double *S, double mu,
+                                 double *theta)
+{
+    double lg = 0.0, th = 0.0;
+    for (int i = 0; i < w->N * w->nx; i++) th += fabs(C[i]);
+    for (int k = 0; k <= w->N; k++)
+        for (int s = 0; s < w->nh; s++)
+            if (slot_active(w, k, s)) { size_t o = (size_t)k * w->nh + s; lg += log(S[o]); th += fabs(H[o] - S[o]); }
+    *theta = th;
+    return f - mu * lg;
+}
+
+/* Cholesky of the leading n x n of a (row-major, ld), in place (lower). 0 = ok, 1 = not positive definite */
+static int chol(double *a, int n, int ld)
+{
+    for (int j = 0; j < n; j++) {
+        double d0 = a[j * ld + j], d = d0;
+        for (int t = 0; t < j; t++) d -= a[j * ld + t] * a[j * ld + t];
+        if (!(d > 1e-9 * fabs(d0)) || !(d > 0.0)) return 1;
+        d = sqrt(d); a[j * ld + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double v = a[i * ld + j];
+            for (int t = 0; t < j; t++) v -= a[i * ld + t] * a[j * ld + t];
+            a[i * ld + j] = v / d;
+        }
+    }
+    return 0;
+}
+
+static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, double *obj_out, int *iters_out, double *kkt_out)
+{
+    const int nx = w->nx, nu = w->nu, N = w->N, m = w->m, nh = w->nh;
+    const double *x0p = p, *xs = p + nx;
+    const double T = w->T;
+    int status = NMPC_STATUS_MAX_ITER;
+    memcpy(w->X, w0, sizeof(double) * (size_t)(N + 1) * nx);
+    memcpy(w->U, w0 + (size_t)(N + 1) * nx, sizeof(double) * (size_t)N * nu);
+    memcpy(w->X, x0p, sizeof(double) * nx);
+
+    /* stage-0 pair / obstacle rows act on the pinned state: feasibility pre-check */
+    int infeasible = 0;
+    for (int pq = 0; pq < w->M; pq++) {
+        int i = w->pi[pq], j = w->pj[pq];
+        double dx = x0p[3 * i] - x0p[3 * j], dy = x0p[3 * i + 1] - x0p[3 * j + 1];
+        if (dx * dx + dy * dy < w->dmin2) infeasible = 1;
+    }
+    for (int i = 0; i < m; i++)
+        for (int o = 0; o < w->K; o++) {
+            double dx = x0p[3 * i] - w->obs[3 * o], dy = x0p[3 * i + 1] - w->obs[3 * o + 1];
+            if (sqrt(dx * dx + dy * dy) - w->robdim - w->obs[3 * o + 2] < w->margin) infeasible = 1;
+        }
+    if (infeasible) {
+        memcpy(wout, w->X, sizeof(double) * (size_t)(N + 1) * nx);
+        memcpy(wout + (size_t)(N + 1) * nx, w->U, sizeof(double) * (size_t)N * nu);
+        *obj_out = NAN; *iters_out = 0; *kkt_out = INFINITY;
+        return NMPC_STATUS_INFEASIBLE_X0;
+    }
+
+    /* push the start strictly inside the simple bounds (IPOPT bound_push = bound_frac = 1e-2) */
+    const double bp = 1e-2;
+    for (int k = 0; k < N; k++)
+        for (int c = 0; c < nu; c++) {
+            double lo = w->lbu[c], hi = w->ubu[c];
+            double pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+            double *u = &w->U[(size_t)k * nu + c];
+            *u = fmin(fmax(*u, lo + pu), hi - pu);
+        }
+    for (int k = 1; k <= N; k++)
+        for (int s = 0; s < w->nxb; s++) {
+            double b = w->bxs[s], px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+            double *x = &w->X[(size_t)k * nx + w->bidx[s]];
+            *x = fmin(fmax(*x, -b + px), b - px);
+        }
+
+    double mu = w->mu_init;
+    double f = eval_point(w, xs, w->X, w->U, w->sn, w->cs, w->C, w->H);
+    for (int k = 0; k <= N; k++)
+        for (int s = 0; s < nh; s++) {
+            size_t o = (size_t)k * nh + s;
+            if (!slot_active(w, k, s)) { w->S[o] = 1.0; w->Z[o] = 0.0; continue; }
+            double floor_ = (s < w->o_xl) ? 1e-12 : bp;
+            w->S[o] = fmax(w->H[o], floor_);
+            w->Z[o] = mu / w->S[o];
+        }
+    memset(w->lam, 0, sizeof(double) * (size_t)(N + 1) * nx);
+    double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    int it = 0;
+    int n_ineq = 0;
+    for (int k = 0; k <= N; k++) for (int s = 0; s < nh; s++) n_ineq += slot_active(w, k, s);
+    double tmp[NXM + NUM_], Jd[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
+
+    for (;;) {
+        /* ---- stationarity residual and optimality error (IPOPT eq. 5) */
+        double e_d = 0.0, e_c = 0.0, e_h = 0.0, zsum = 0.0, lsum = 0.0;
+        for (int k = 1; k <= N; k++) {
+            const double *x = w->X + (size_t)k * nx;
+            double r[NXM];
+            for (int c = 0; c < nx; c++) r[c] = w->lam[(size_t)k * nx + c];
+            if (k < N) {
+                const double *ln = w->lam + (size_t)(k + 1) * nx, *u = w->U + (size_t)k * nu;
+                for (int i = 0; i < m; i++) {
+                    double a = -T * u[2 * i] * w->sn[k * m + i], b = T * u[2 * i] * w->cs[k * m + i];
+                    r[3 * i] += 2 * w->qd[3 * i] * (x[3 * i] - xs[3 * i]) - ln[3 * i];
+                    r[3 * i + 1] += 2 * w->qd[3 * i + 1] * (x[3 * i + 1] - xs[3 * i + 1]) - ln[3 * i + 1];
+                    r[3 * i + 2] += 2 * w->qd[3 * i + 2] * (x[3 * i + 2] - xs[3 * i + 2]) - (ln[3 * i + 2] + a * ln[3 * i] + b * ln[3 * i + 1]);
+                }
+            }
+            for (int c = 0; c < nx; c++) tmp[c] = 0.0;
+            jxT_apply(w, k, x, w->Z + (size_t)k * nh, tmp);
+            for (int c = 0; c < nx; c++) { r[c] -= tmp[c]; e_d = fmax(e_d, fabs(r[c])); }
+        }
+        for (int k = 0; k < N; k++) {
+            const double *ln = w->lam + (size_t)(k + 1) * nx, *u = w->U + (size_t)k * nu, *z = w->Z + (size_t)k * nh;
+            for (int i = 0; i < m; i++) {
+                double c = w->cs[k * m + i], s = w->sn[k * m + i];
+                double rv = 2 * w->rd[2 * i] * u[2 * i] - T * (c * ln[3 * i] + s * ln[3 * i + 1]) - (z[w->o_ul + 2 * i] - z[w->o_uu + 2 * i]);
+                double rw = 2 * w->rd[2 * i + 1] * u[2 * i + 1] - T * ln[3 * i + 2] - (z[w->o_ul + 2 * i + 1] - z[w->o_uu + 2 * i + 1]);
+                e_d = fmax(e_d, fmax(fabs(rv), fabs(rw)));
+            }
+        }
+        for (int i = 0; i < N * nx; i++) e_c = fmax(e_c, fabs(w->C[i]));
+        for (int i = nx; i < (N + 1) * nx; i++) lsum += fabs(w->lam[i]);
+        double cmp0 = 0.0;
+        for (int k = 0; k <= N; k++)
+            for (int s = 0; s < nh; s++)
+                if (slot_active(w, k, s)) {
+                    size_t o = (size_t)k * nh + s;
+                    e_h = fmax(e_h, fabs(w->H[o] - w->S[o]));
+                    zsum += w->Z[o];
+                    cmp0 = fmax(cmp0, w->S[o] * w->Z[o]);
+                }
+        const double smax = 100.0;
+        double s_d = fmax(smax, (lsum + zsum) / (double)(N * nx + n_ineq)) / smax;
+        double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
+        double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmp0 / s_c));
+        kkt = E0;
+        if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+        if (E0 <= w->tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (it >= w->max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+        /* ---- monotone barrier update (IPOPT eq. 7) */
+        const double mu_min = w->tol / 10.0;
+        for (;;) {
+            double cm = 0.0;
+            for (int k = 0; k <= N; k++)
+                for (int s = 0; s < nh; s++)
+                    if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; cm = fmax(cm, fabs(w->S[o] * w->Z[o] - mu)); }
+            double Emu = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cm / s_c));
+            if (mu > mu_min && Emu <= 10.0 * mu) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
+            else break;
+        }
+        double tau = fmax(0.99, 1.0 - mu);
+
+        /* ---- condensed stage blocks: Hxx, gx (k=1..N), diagonal huu, gu, cross term hvt (k=0..N-1) */
+        for (int k = 0; k <= N; k++) {
+            const double *x = w->X + (size_t)k * nx, *s_ = w->S + (size_t)k * nh, *z = w->Z + (size_t)k * nh, *h = w->H + (size_t)k * nh;
+            double *Hk = w->Hxx + (size_t)k * nx * nx, *g = w->gx + (size_t)k * nx;
+            memset(Hk, 0, sizeof(double) * nx * nx);
+            for (int c = 0; c < nx; c++) g[c] = 0.0;
+            if (k >= 1) {
+                if (k < N)
+                    for (int c = 0; c < nx; c++) { Hk[c * nx + c] = 2 * w->qd[c]; g[c] = 2 * w->qd[c] * (x[c] - xs[c]); }
+                /* v = mu/s - sigma (h - s) per slot; g -= Jx^T v; Hxx += Jx^T Sigma Jx - z * hess(h) */
+                double v[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
+                for (int s = 0; s < nh; s++) v[s] = slot_active(w, k, s) ? (mu / s_[s] - z[s] / s_[s] * (h[s] - s_[s])) : 0.0;
+                for (int c = 0; c < nx; c++) tmp[c] = 0.0;
+                jxT_apply(w, k, x, v, tmp);
+                for (int c = 0; c < nx; c++) g[c] -= tmp[c];
+                for (int s = 0; s < w->nxb; s++) {
+                    int c = w->bidx[s];
+                    Hk[c * nx + c] += z[w->o_xl + s] / s_[w->o_xl + s] + z[w->o_xu + s] / s_[w->o_xu + s];
+                }
+                if (k <= N - 1) {
+                    for (int pq = 0; pq < w->M; pq++) {
+                        int i = w->pi[pq], j = w->pj[pq];
+                        double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
+                        double sg = z[w->o_pr + pq] / s_[w->o_pr + pq], zz = z[w->o_pr + pq];
+                        double e00 = 4 * sg * dx * dx - 2 * zz, e01 = 4 * sg * dx * dy, e11 = 4 * sg * dy * dy - 2 * zz;
+                        int a = 3 * i, b = 3 * j;
+                        Hk[a * nx + a] += e00; Hk[a * nx + a + 1] += e01; Hk[(a + 1) * nx + a] += e01; Hk[(a + 1) * nx + a + 1] += e11;
+                        Hk[b * nx + b] += e00; Hk[b * nx + b + 1] += e01; Hk[(b + 1) * nx + b] += e01; Hk[(b + 1) * nx + b + 1] += e11;
+                        Hk[a * nx + b] -= e00; Hk[a * nx + b + 1] -= e01; Hk[(a + 1) * nx + b] -= e01; Hk[(a + 1) * nx + b + 1] -= e11;
+                        Hk[b * nx + a] -= e00; Hk[b * nx + a + 1] -= e01; Hk[(b + 1) * nx + a] -= e01; Hk[(b + 1) * nx + a + 1] -= e11;
+                    }
+                    for (int i = 0; i < m; i++)
+                        for (int o = 0; o < w->K; o++) {
+                            double dx = x[3 * i] - w->obs[3 * o], dy = x[3 * i + 1] - w->obs[3 * o + 1];
+                            double rr = sqrt(dx * dx + dy * dy), n0 = dx / rr, n1 = dy / rr;
+                            int sl = w->o_ob + i * w->K + o;
+                            double sg = z[sl] / s_[sl], zz = z[sl] / rr;
+                            int a = 3 * i;
+                            Hk[a * nx + a] += sg * n0 * n0 - zz * (1 - n0 * n0);
+                            Hk[a * nx + a + 1] += sg * n0 * n1 + zz * n0 * n1;
+                            Hk[(a + 1) * nx + a] += sg * n0 * n1 + zz * n0 * n1;
+                            Hk[(a + 1) * nx + a + 1] += sg * n1 * n1 - zz * (1 - n1 * n1);
+                        }
+                }
+            }
+            if (k < N) {
+                const double *u = w->U + (size_t)k * nu, *ln = w->lam + (size_t)(k + 1) * nx;
+                for (int c = 0; c < nu; c++) {
+                    double sl = s_[w->o_ul + c], su = s_[w->o_uu + c], zl = z[w->o_ul + c], zu = z[w->o_uu + c];
+                    w->huu[k * nu + c] = 2 * w->rd[c] + zl / sl + zu / su;
+                    double vl = mu / sl - zl / sl * (h[w->o_ul + c] - sl), vu = mu / su - zu / su * (h[w->o_uu + c] - su);
+                    w->gu[k * nu + c] = 2 * w->rd[c] * u[c] - (vl - vu);
+                }
+                for (int i = 0; i < m; i++) {
+                    double c = w->cs[k * m + i], s = w->sn[k * m + i], lx = ln[3 * i], ly = ln[3 * i + 1];
+                    if (k >= 1) Hk[(3 * i + 2) * nx + 3 * i + 2] += T * u[2 * i] * (lx * c + ly * s);
+                    w->hvt[k * m + i] = T * (lx * s - ly * c);
+                }
+            }
+        }
+
+        /* ---- Riccati sweep with inertia correction (IPOPT alg. IC) */
+        double delta = 0.0;
+        int ntry = 0, ok = 0;
+        double P[NXM * NXM], pv[NXM], G[NXM * (NXM + NUM_)], Qxx[NXM * NXM], Qux[NUM_ * NXM], Quu[NUM_ * NUM_], Pb[NXM], qx[NXM], qu[NUM_];
+        for (;;) {
+            ok = 1;
+            memcpy(P, w->Hxx + (size_t)N * nx * nx, sizeof(double) * nx * nx);
+            for (int c = 0; c < nx; c++) { P[c * nx + c] += delta; pv[c] = w->gx[(size_t)N * nx + c]; }
+            for (int k = N - 1; k >= 0; k--) {
+                const double *u = w->U + (size_t)k * nu, *Ck = w->C + (size_t)k * nx;
+                const int nz = nx + nu;
+                /* Pb = p + P b, b = -c_k */
+                for (int r = 0; r < nx; r++) { double a = pv[r]; for (int c = 0; c < nx; c++) a -= P[r * nx + c] * Ck[c]; Pb[r] = a; }
+                /* G = P [A B]  (A = I + sparse, B sparse: per-robot column combinations) */
+                for (int r = 0; r < nx; r++) {
+                    const double *Pr = P + r * nx; double *Gr = G + r * nz;
+                    for (int i = 0; i < m; i++) {
+                        double c = w->cs[k * m + i], s = w->sn[k * m + i], a = -T * u[2 * i] * s, b = T * u[2 * i] * c;
+                        Gr[3 * i] = Pr[3 * i]; Gr[3 * i + 1] = Pr[3 * i + 1];
+                        Gr[3 * i + 2] = Pr[3 * i + 2] + a * Pr[3 * i] + b * Pr[3 * i + 1];
+                        Gr[nx + 2 * i] = T * (c * Pr[3 * i] + s * Pr[3 * i + 1]);
+                        Gr[nx + 2 * i + 1] = T * Pr[3 * i + 2];
+                    }
+                }
+                /* [Qxx Qxu; Qux Quu] = [A B]^T G + H ; q = g + [A B]^T Pb */
+                for (int i = 0; i < m; i++) {
+                    double c = w->cs[k * m + i], s = w->sn[k * m + i], a = -T * u[2 * i] * s, b = T * u[2 * i] * c;
+                    const double *Gx = G + (3 * i) * nz, *Gy = G + (3 * i + 1) * nz, *Gt = G + (3 * i + 2) * nz;
+                    for (int cc = 0; cc < nx; cc++) {
+                        Qxx[(3 * i) * nx + cc] = Gx[cc]; Qxx[(3 * i + 1) * nx + cc] = Gy[cc];
+                        Qxx[(3 * i + 2) * nx + cc] = Gt[cc] + a * Gx[cc] + b * Gy[cc];
+                        Qux[(2 * i) * nx + cc] = T * (c * Gx[cc] + s * Gy[cc]);
+                        Qux[(2 * i + 1) * nx + cc] = T * Gt[cc];
+                    }
+                    for (int cc = 0; cc < nu; cc++) {
+                        Quu[(2 * i) * nu + cc] = T * (c * Gx[nx + cc] + s * Gy[nx + cc]);
+                        Quu[(2 * i + 1) * nu + cc] = T * Gt[nx + cc];
+                    }
+                    qx[3 * i] = Pb[3 * i]; qx[3 * i + 1] = Pb[3 * i + 1]; qx[3 * i + 2] = Pb[3 * i + 2] + a * Pb[3 * i] + b * Pb[3 * i + 1];
+                    qu[2 * i] = T * (c * Pb[3 * i] + s * Pb[3 * i + 1]); qu[2 * i + 1] = T * Pb[3 * i + 2];
+                }
+                for (int c = 0; c < nu; c++) { Quu[c * nu + c] += w->huu[k * nu + c] + delta; qu[c] += w->gu[k * nu + c]; }
+                for (int i = 0; i < m; i++) Qux[(2 * i) * nx + 3 * i + 2] += w->hvt[k * m + i];
+                if (chol(Quu, nu, nu)) { ok = 0; break; }
+                /* Y = L^-1 Qux, y = L^-1 qu (forward substitution) */
+                for (int r = 0; r < nu; r++) {
+                    for (int t = 0; t < r; t++) {
+                        double l = Quu[r * nu + t];
+                        for (int c = 0; c < nx; c++) Qux[r * nx + c] -= l * Qux[t * nx + c];
+                        qu[r] -= l * qu[t];
+                    }
+                    double d = Quu[r * nu + r];
+                    for (int c = 0; c < nx; c++) Qux[r * nx + c] /= d;
+                    qu[r] /= d;
+                }
+                if (k >= 1) {
+                    const double *Hk = w->Hxx + (size_t)k * nx * nx;
+                    for (int r = 0; r < nx; r++) {
+                        for (int c = 0; c < nx; c++) {
+                            double a = Qxx[r * nx + c] + Hk[r * nx + c];
+                            for (int t = 0; t < nu; t++) a -= Qux[t * nx + r] * Qux[t * nx + c];
+                            P[r * nx + c] = a;
+                        }
+                        P[r * nx + r] += delta;
+                        double a = qx[r] + w->gx[(size_t)k * nx + r];
+                        for (int t = 0; t < nu; t++) a -= Qux[t * nx + r] * qu[t];
+                        pv[r] = a;
+                    }
+                    for (int i = 0; i < m; i++) {           /* cross term Hxu enters Qxx via (theta_i, v_i): handled through Qux above */
+                        (void)i;
+                    }
+                    for (int r = 0; r < nx; r++) for (int c = r + 1; c < nx; c++) { double a = 0.5 * (P[r * nx + c] + P[c * nx + r]); P[r * nx + c] = a; P[c * nx + r] = a; }
+                }
+                /* K = -L^-T Y, kff = -L^-T y (back substitution) */
+                double *Kk = w->Kg + (size_t)k * nu * nx, *kk = w->kff + (size_t)k * nu;
+                for (int r = nu - 1; r >= 0; r--) {
+                    double d = Quu[r * nu + r];
+                    for (int c = 0; c < nx; c++) {
+                        double a = Qux[r * nx + c];
+                        for (int t = r + 1; t < nu; t++) a += Quu[t * nu + r] * Kk[t * nx + c];
+                        Kk[r * nx + c] = -a / d;
+                    }
+                    double a = qu[r];
+                    for (int t = r + 1; t < nu; t++) a += Quu[t * nu + r] * kk[t];
+                    kk[r] = -a / d;
+                }
+            }
+            if (ok) break;
+            ntry++;
+            if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
+            else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+            if (delta > 1e20) break;
+        }
+        if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+        if (delta > 0.0) delta_last = delta;
+
+        /* ---- forward sweep */
+        for (int c = 0; c < nx; c++) w->dX[c] = 0.0;
+        for (int k = 0; k < N; k++) {
+            const double *dx = w->dX + (size_t)k * nx, *u = w->U + (size_t)k * nu;
+            double *du = w->dU + (size_t)k * nu, *dxn = w->dX + (size_t)(k + 1) * nx;
+            for (int r = 0; r < nu; r++) {
+                double a = w->kff[k * nu + r];
+                for (int c = 0; c < nx; c++) a += w->Kg[((size_t)k * nu + r) * nx + c] * dx[c];
+                du[r] = a;
+            }
+            for (int i = 0; i < m; i++) {
+                double c = w->cs[k * m + i], s = w->sn[k * m + i], a = -T * u[2 * i] * s, b = T * u[2 * i] * c;
+                dxn[3 * i] = dx[3 * i] + a * dx[3 * i + 2] + T * c * du[2 * i] - w->C[k * nx + 3 * i];
+                dxn[3 * i + 1] = dx[3 * i + 1] + b * dx[3 * i + 2] + T * s * du[2 * i] - w->C[k * nx + 3 * i + 1];
+                dxn[3 * i + 2] = dx[3 * i + 2] + T * du[2 * i + 1] - w->C[k * nx + 3 * i + 2];
+            }
+        }
+        /* ---- multipliers of the QP by the adjoint recursion */
+        for (int k = N; k >= 1; k--) {
+            const double *Hk = w->Hxx + (size_t)k * nx * nx, *dx = w->dX + (size_t)k * nx;
+            double *l = w->lamn + (size_t)k * nx;
+            for (int r = 0; r < nx; r++) {
+                double a = w->gx[(size_t)k * nx + r] + delta * dx[r];
+                for (int c = 0; c < nx; c++) a += Hk[r * nx + c] * dx[c];
+                l[r] = -a;
+            }
+            if (k < N) {
+                const double *ln = w->lamn + (size_t)(k + 1) * nx, *u = w->U + (size_t)k * nu, *du = w->dU + (size_t)k * nu;
+                for (int i = 0; i < m; i++) {
+                    double a = -T * u[2 * i] * w->sn[k * m + i], b = T * u[2 * i] * w->cs[k * m + i];
+                    l[3 * i] += ln[3 * i]; l[3 * i + 1] += ln[3 * i + 1];
+                    l[3 * i + 2] += ln[3 * i + 2] + a * ln[3 * i] + b * ln[3 * i + 1] - w->hvt[k * m + i] * du[2 * i];
+                }
+            }
+        }
+        /* ---- slack / dual steps and fraction to the boundary (IPOPT eq. 15) */
+        double a_p = 1.0, a_d = 1.0;
+        for (int k = 0; k <= N; k++) {
+            j_apply(w, k, w->X + (size_t)k * nx, w->dX + (size_t)k * nx, k < N ? w->dU + (size_t)k * nu : NULL, Jd);
+            for (int s = 0; s < nh; s++) {
+                size_t o = (size_t)k * nh + s;
+                if (!slot_active(w, k, s)) { w->dS[o] = 0.0; w->dZ[o] = 0.0; continue; }
+                double ds = Jd[s] + (w->H[o] - w->S[o]);
+                double dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o];
+                w->dS[o] = ds; w->dZ[o] = dz;
+                if (ds < 0.0) a_p = fmin(a_p, -tau * w->S[o] / ds);
+                if (dz < 0.0) a_d = fmin(a_d, -tau * w->Z[o] / dz);
+            }
+        }
+        /* ---- l1 merit backtracking */
+        double th0, phi0 = barrier_and_infeas(w, f, w->C, w->H, w->S, mu, &th0);
+        double dphi = 0.0;
+        for (int k = 0; k <= N; k++) {
+            const double *x = w->X + (size_t)k * nx;
+            if (k >= 1 && k < N) for (int c = 0; c < nx; c++) dphi += 2 * w->qd[c] * (x[c] - xs[c]) * w->dX[(size_t)k * nx + c];
+            if (k < N) for (int c = 0; c < nu; c++) dphi += 2 * w->rd[c] * w->U[(size_t)k * nu + c] * w->dU[(size_t)k * nu + c];
+            for (int s = 0; s < nh; s++) if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; dphi -= mu * w->dS[o] / w->S[o]; }
+        }
+        if (th0 > 0.0) {
+            double nut = dphi / ((1.0 - 0.1) * th0);
+            if (nu_pen < nut) nu_pen = nut + 1.0;
+        }
+        double D = dphi - nu_pen * th0, alpha = a_p, ft = f;
+        for (int ls = 0; ls < 30; ls++) {
+            for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
+            for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
+            for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + alpha * w->dS[i];
+            ft = eval_point(w, xs, w->Xt, w->Ut, w->snt, w->cst, w->Ct, w->Ht);
+            double tht, phit = barrier_and_infeas(w, ft, w->Ct, w->Ht, w->St, mu, &tht);
+            if (phit + nu_pen * tht <= phi0 + nu_pen * th0 + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
+            if (ls < 29) alpha *= 0.5;
+        }
+        /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
+        { double *t;
+          t = w->X; w->X = w->Xt; w->Xt = t; t = w->U; w->U = w->Ut; w->Ut = t; t = w->S; w->S = w->St; w->St = t;
+          t = w->C; w->C = w->Ct; w->Ct = t; t = w->H; w->H = w->Ht; w->Ht = t;
+          t = w->sn; w->sn = w->snt; w->snt = t; t = w->cs; w->cs = w->cst; w->cst = t; }
+        f = ft;
+        for (int k = 0; k <= N; k++)
+            for (int s = 0; s < nh; s++)
+                if (slot_active(w, k, s)) {
+                    size_t o = (size_t)k * nh + s;
+                    double z = w->Z[o] + a_d * w->dZ[o];
+                    double lo = mu / (1e10 * w->S[o]), hi = 1e10 * mu / w->S[o];
+                    w->Z[o] = fmin(fmax(z, lo), hi);
+                }
+        for (size_t i = nx; i < (size_t)(N + 1) * nx; i++) w->lam[i] += alpha * (w->lamn[i] - w->lam[i]);
+        it++;
+    }
+    memcpy(wout, w->X, sizeof(double) * (size_t)(N + 1) * nx);
+    memcpy(wout + (size_t)(N + 1) * nx, w->U, sizeof(double) * (size_t)N * nu);
+    *obj_out = f; *iters_out = it; *kkt_out = kkt;
+    return status;
+}
+
+/* ---- exported test/baseline entry points ------------------------------------------------- */
+
+int32_t nmpc_oracle_solve_batch(const nmpc_config_t *cfg, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
+                                int32_t *status, int32_t *iters, double *kkt, int32_t nthreads)
+{
+    if (!cfg || cfg->m < 1 || cfg->m > NMPC_MAX_ROBOTS || cfg->N < 1 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
+    const int nv = nmpc_n_var(cfg), np_ = nmpc_n_p(cfg);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        ws_t *w = ws_new(cfg);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            double o = 0, k = 0; int it = 0;
+            int st = solve_one(w, p + (size_t)b * np_, w0 + (size_t)b * nv, w_out + (size_t)b * nv, &o, &it, &k);
+            if (obj) obj[b] = o;
+            if (status) status[b] = st;
+            if (iters) iters[b] = it;
+            if (kkt) kkt[b] = k;
+        }
+        ws_free(w);
+    }
+    return NMPC_OK;
+}
+
+/* f and g in the reference's row order (C6:278,314,318-331) */
+int32_t nmpc_oracle_eval_batch(const nmpc_config_t *cfg, int32_t B, const double *p, const double *wv, double *f, double *g)
+{
+    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, M = m * (m - 1) / 2, K = cfg->n_obs;
+    const int nv = nmpc_n_var(cfg), ng = nmpc_n_g(cfg);
+    for (int b = 0; b < B; b++) {
+        const double *X = wv + (size_t)b * nv, *U = X + (size_t)(N + 1) * nx, *pp = p + (size_t)b * 2 * nx;
+        double fv = 0.0;
+        double *gg = g ? g + (size_t)b * ng : NULL;
+        int o = 0;
+        if (gg) {
+            for (int c = 0; c < nx; c++) gg[o++] = X[c] - pp[c];
+            if (cfg->pad_rows) for (int c = 0; c < M; c++) gg[o++] = cfg->pad_value;
+        }
+        for (int k = 0; k < N; k++) {
+            const double *x = X + (size_t)k * nx, *xn = x + nx, *u = U + (size_t)k * nu;
+            for (int i = 0; i < m; i++) {
+                for (int d = 0; d < 3; d++) { double e = x[3 * i + d] - pp[nx + 3 * i + d]; fv += cfg->q[d] * e * e; }
+                fv += cfg->r[0] * u[2 * i] * u[2 * i] + cfg->r[1] * u[2 * i + 1] * u[2 * i + 1];
+                if (gg) {
+                    gg[o++] = xn[3 * i] - (x[3 * i] + cfg->T * u[2 * i] * cos(x[3 * i + 2]));
+                    gg[o++] = xn[3 * i + 1] - (x[3 * i + 1] + cfg->T * u[2 * i] * sin(x[3 * i + 2]));
+                    gg[o++] = xn[3 * i + 2] - (x[3 * i + 2] + cfg->T * u[2 * i + 1]);
+                }
+            }
+            if (gg) {
+                for (int i = 0; i < m; i++)
+                    for (int j = i + 1; j < m; j++) {
+                        double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
+                        gg[o++] = dx * dx + dy * dy;
+                    }
+                for (int i = 0; i < m; i++)
+                    for (int q = 0; q < K; q++) {
+                        double dx = x[3 * i] - cfg->obs[3 * q], dy = x[3 * i + 1] - cfg->obs[3 * q + 1];
+                        gg[o++] = sqrt(dx * dx + dy * dy) - cfg->rob_dim - cfg->obs[3 * q + 2];
+                    }
+            }
+        }
+        if (f) f[b] = fv;
+    }
+    return NMPC_OK;
+}
+
+/* warm-start shift (C6:160-169,460-465) and optional plant step (casadi_test.py:17-26) */
+int32_t nmpc_oracle_shift_batch(const nmpc_config_t *cfg, int32_t B, const double *p_in, const double *w_in, double *w_next,
+                                double *x0_next)
+{
+    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, nv = nmpc_n_var(cfg);
+    for (int b = 0; b < B; b++) {
+        const double *X = w_in + (size_t)b * nv, *U = X + (size_t)(N + 1) * nx;
+        double *Xn = w_next + (size_t)b * nv, *Un = Xn + (size_t)(N + 1) * nx;
+        for (int k = 0; k < N; k++) memcpy(Xn + (size_t)k * nx, X + (size_t)(k + 1) * nx, sizeof(double) * nx);
+        memcpy(Xn + (size_t)N * nx, X + (size_t)(N - 1) * nx, sizeof(double) * nx);
+        for (int k = 0; k < N - 1; k++) memcpy(Un + (size_t)k * nu, U + (size_t)(k + 1) * nu, sizeof(double) * nu);
+        memcpy(Un + (size_t)(N - 1) * nu, U + (size_t)(N - 1) * nu, sizeof(double) * nu);
+        if (x0_next) {
+            const double *x0 = p_in + (size_t)b * 2 * nx;
+            for (int i = 0; i < m; i++) {
+                x0_next[(size_t)b * nx + 3 * i] = x0[3 * i] + cfg->T * U[2 * i] * cos(x0[3 * i + 2]);
+                x0_next[(size_t)b * nx + 3 * i + 1] = x0[3 * i + 1] + cfg->T * U[2 * i] * sin(x0[3 * i + 2]);
+                x0_next[(size_t)b * nx + 3 * i + 2] = x0[3 * i + 2] + cfg->T * U[2 * i + 1];
+            }
+        }
+    }
+    return NMPC_OK;
+}
+
+int32_t nmpc_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

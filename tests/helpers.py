@@ -1,0 +1,42 @@
+"""Synthetic instance generator of SURVEY.md §8(d): PCG64(seed = 20210141 + config_index)."""
+import numpy as np
+
+from oracle import nlp_ref as R
+
+SEED0 = 20210141
+
+
+def sample_points(rng, m, dsep, lim=2.0, obstacles=(), clear=0.0):
+    pts = []
+    while len(pts) < m:
+        c = rng.uniform(-lim, lim, 2)
+        if all(np.hypot(*(c - q)) >= dsep for q in pts) and all(np.hypot(c[0] - ox, c[1] - oy) >= clear + orad for (ox, oy, orad) in obstacles):
+            pts.append(c)
+    return np.array(pts)
+
+
+def instance(rng, cfg):
+    """p = [x0; xs]: starts/goals uniform in [-2,2]^2 with pairwise distance >= dmin + 0.1, theta uniform."""
+    m = cfg.m
+    dsep = cfg.dmin + 0.1
+    clear = cfg.rob_dim + cfg.margin + 0.05
+    s = sample_points(rng, m, dsep, obstacles=cfg.obstacles, clear=clear)
+    g = sample_points(rng, m, dsep, obstacles=cfg.obstacles, clear=clear)
+    x0 = np.concatenate([s, rng.uniform(-np.pi, np.pi, (m, 1))], axis=1).reshape(-1)
+    xs = np.concatenate([g, rng.uniform(-np.pi, np.pi, (m, 1))], axis=1).reshape(-1)
+    return np.concatenate([x0, xs])
+
+
+def batch(cfg, B, config_index):
+    rng = np.random.Generator(np.random.PCG64(SEED0 + config_index))
+    P = np.stack([instance(rng, cfg) for _ in range(B)])
+    W0 = np.stack([R.cold_start(cfg, p[: cfg.nx]) for p in P])
+    return P, W0
+
+
+def to_product_cfg(ocfg, **kw):
+    """oracle NLPConfig -> product ProblemConfig (two independent definitions of the same literals)."""
+    import nmpc_amd
+    return nmpc_amd.ProblemConfig(m=ocfg.m, N=ocfg.N, T=ocfg.T, dmin=ocfg.dmin, q=tuple(ocfg.q), r=tuple(ocfg.r), v_max=ocfg.v_max,
+                                  w_max=ocfg.w_max, xy_max=ocfg.xy_max, th_max=ocfg.th_max, obstacles=list(ocfg.obstacles),
+                                  rob_dim=ocfg.rob_dim, margin=ocfg.margin, pad_value=ocfg.pad_value, pad_rows=ocfg.pad_rows, **kw)

@@ -1,0 +1,154 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64 path, north_star "within a stated FP tolerance"):
+  * same-basin instances: max |w_hip - w_oracle| <= 1e-6 (m, rad, m/s, rad/s); |f_hip - f_oracle| <= 1e-6 * max(1,|f|)
+  * every instance: reported KKT error <= tol = 1e-8, and for a sample the independent
+    least-squares KKT check of oracle/nlp_ref.kkt_report.
+The NLP is non-convex: two correct solvers may land in different local minima,
+so the iterate-level comparison is required on >= 85 % of a random batch, the rest must be
+valid KKT points themselves.
+"""
+import numpy as np
+import pytest
+
+from oracle import nlp_ref as R, oracle_lib as O
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+W_TOL = 1e-6
+F_RTOL = 1e-6
+
+
+def _solver(ocfg, B, max_iter=400):
+    import nmpc_amd
+    cfg = Hh.to_product_cfg(ocfg, max_iter=max_iter)
+    return nmpc_amd.NmpcSolver(cfg, max_batch=B)
+
+
+def _np(r):
+    return {k: v.cpu().numpy() for k, v in r.items()}
+
+
+@pytest.mark.parametrize("name,ocfg,B,idx", [
+    ("one", R.cfg_one(20), 64, 0), ("two", R.cfg_two(20), 128, 1), ("six", R.cfg_six(20), 96, 2),
+    ("ten", R.cfg_ten(20), 16, 3), ("obs3", R.cfg_obs3(20), 32, 4),
+])
+def test_solve_matches_oracle(built, name, ocfg, B, idx):
+    import torch
+    P, W0 = Hh.batch(ocfg, B, idx)
+    if name == "obs3":   # walk the robot through the obstacle field of the script
+        P = np.stack([np.array([0.3 * np.cos(t), 0.6 + 0.02 * t, 1.2, 0.2 * np.sin(t), 3.9, 1.57]) for t in range(B)])
+        W0 = np.stack([R.cold_start(ocfg, p[:3]) for p in P])
+    s = _solver(ocfg, B)
+    r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=400), P, W0)
+    assert (r["status"] == 0).all(), (r["status"], r["iters"])
+    assert (ref["status"] == 0).all()
+    assert (r["kkt"] <= 1e-8).all()
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    same = dw <= W_TOL
+    frac = same.mean()
+    print(f"{name}: same-basin {frac:.3f}, iters hip mean {r['iters'].mean():.1f} max {r['iters'].max()}, oracle mean {ref['iters'].mean():.1f}")
+    assert frac >= 0.85, (name, frac, dw)
+    rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
+    assert (rel[same] <= F_RTOL).all()
+    # instances that ended in another basin must still be KKT points (independent check)
+    for b in np.where(~same)[0][:4]:
+        k = R.kkt_report(ocfg, r["x"][b], P[b])
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
+    # x0 is pinned and bounds hold exactly
+    assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
+    lbx, ubx, _, _ = R.bounds(ocfg)
+    assert (r["x"] >= lbx - 1e-12).all() and (r["x"] <= ubx + 1e-12).all()
+
+
+def test_polish_from_oracle_solution(built):
+    """KKT-point parity independent of the path: started at the oracle's optimum the HIP solve returns it."""
+    import torch
+    ocfg = R.cfg_six(20)
+    P, W0 = Hh.batch(ocfg, 32, 2)
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=400), P, W0)
+    s = _solver(ocfg, 32)
+    r = _np(s.solve_batch(P, ref["x"])); torch.cuda.synchronize()
+    assert (r["status"] == 0).all()
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    assert (dw <= 1e-5).mean() >= 0.9, dw
+
+
+def test_literal_scenarios(built):
+    """the reference's own start/goal sets (C2:213-224, C6:364-388) as instance 0."""
+    import torch
+    for ocfg, start, goal in ((R.cfg_two(20), R.C2_START, R.C2_GOAL), (R.cfg_six(20), R.C6_START, R.C6_GOAL)):
+        p = np.concatenate([start, goal])[None]
+        w0 = R.cold_start(ocfg, start)[None]
+        s = _solver(ocfg, 1, max_iter=600)
+        r = _np(s.solve_batch(p, w0)); torch.cuda.synchronize()
+        assert r["status"][0] == 0, (r["status"], r["iters"], r["kkt"])
+        k = R.kkt_report(ocfg, r["x"][0], p[0])
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-7 and k["ineq"] < 1e-7, k
+
+
+def test_infeasible_x0_status(built):
+    """ten-robot literal x0 has coincident robots (C10:389): status 3, warm start returned, no exception."""
+    import torch
+    ocfg = R.cfg_two(20)
+    p = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 1.0, 1.0, 0.0, -1.0, -1.0, 0.0]])
+    w0 = R.cold_start(ocfg, p[0, :6])[None]
+    s = _solver(ocfg, 1)
+    r = _np(s.solve_batch(p, w0)); torch.cuda.synchronize()
+    assert r["status"][0] == 3 and r["iters"][0] == 0
+    assert np.array_equal(r["x"][0], w0[0])
+    ref = O.solve_batch(O.make_config(ocfg), p, w0)
+    assert ref["status"][0] == 3
+
+
+def test_eval_and_shift_kernels(built):
+    """f, g in the reference's row order and the warm-start shift, element-wise against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    for ocfg in (R.cfg_one(20), R.cfg_two(20), R.cfg_six(20), R.cfg_ten(30), R.cfg_obs3(20)):
+        B = 37
+        P = rng.normal(size=(B, 2 * ocfg.nx)); W = rng.normal(size=(B, ocfg.n_var))
+        s = _solver(ocfg, B)
+        f, g = s.eval_batch(P, W); torch.cuda.synchronize()
+        fo, go = O.eval_batch(O.make_config(ocfg), P, W)
+        gn = np.stack([R.constraints(ocfg, W[b], P[b]) for b in range(3)])
+        assert np.max(np.abs(go[:3] - gn)) < 1e-12
+        assert np.max(np.abs(g.cpu().numpy() - go)) <= 1e-12 * max(1.0, np.max(np.abs(go)))
+        assert np.max(np.abs(f.cpu().numpy() - fo) / np.maximum(1, np.abs(fo))) < 1e-12
+        wn, x0n = s.shift_batch(P, W); torch.cuda.synchronize()
+        wno, x0o = O.shift_batch(O.make_config(ocfg), P, W)
+        assert np.array_equal(wn.cpu().numpy(), wno)           # pure data movement: bit-exact
+        assert np.max(np.abs(x0n.cpu().numpy() - x0o)) < 1e-14
+
+
+def test_reference_call_surface(built):
+    """solver(x0=,p=,lbx=,ubx=,lbg=,ubg=) / shift(): the loop of C6:416-465 runs unchanged."""
+    import nmpc_amd
+    ocfg = R.cfg_two(20)
+    cfg = Hh.to_product_cfg(ocfg)
+    opts = {'print_time': 0, 'ipopt': {'max_iter': 2000, 'print_level': 0, 'acceptable_tol': 1e-8, 'acceptable_obj_change_tol': 1e-6}}
+    solver = nmpc_amd.nlpsol('solver', 'ipopt', cfg, opts)
+    lbx, ubx, lbg, ubg = cfg.bounds()
+    args = {'lbg': lbg.reshape(1, -1), 'ubg': ubg.reshape(1, -1), 'lbx': lbx.reshape(-1, 1), 'ubx': ubx.reshape(-1, 1)}
+    N, nx, nu, T = cfg.N, cfg.nx, cfg.nu, cfg.T
+    x0 = R.C2_START.reshape(-1, 1); xs = R.C2_GOAL.reshape(-1, 1)
+    u0 = np.zeros((N, nu)); X0 = np.tile(x0.T, (N + 1, 1)); t0 = 0.0
+    for mpciter in range(3):
+        args['p'] = np.concatenate((x0, xs), axis=0)
+        args['x0'] = np.concatenate((X0.reshape(-1, 1), u0.reshape(-1, 1)), axis=0)
+        sol = solver(x0=args['x0'], p=args['p'], lbx=args['lbx'], ubx=args['ubx'], lbg=args['lbg'], ubg=args['ubg'])
+        assert sol['x'].shape == (cfg.n_var, 1) and sol['g'].shape == (cfg.n_g, 1)
+        assert solver.stats()['success']
+        u = sol['x'][nx * (N + 1):].reshape(N, nu)
+        Xs = sol['x'][: nx * (N + 1)].reshape(N + 1, nx)
+        assert abs(sol['f'] - R.objective(ocfg, sol['x'], args['p'])) < 1e-9 * max(1, abs(sol['f']))
+        assert np.max(np.abs(sol['g'].reshape(-1) - R.constraints(ocfg, sol['x'], args['p']))) < 1e-12
+        t0, u0 = nmpc_amd.shift(T, t0, u)
+        x0 = R.plant_step(ocfg, x0, u[0]).reshape(-1, 1)
+        X0 = nmpc_amd.shift_states(Xs)
+    with pytest.raises(ValueError):
+        solver(x0=args['x0'], p=args['p'], lbx=args['lbx'] * 2)
+    with pytest.raises(ValueError):
+        solver(x0=args['x0'][:-1], p=args['p'])
