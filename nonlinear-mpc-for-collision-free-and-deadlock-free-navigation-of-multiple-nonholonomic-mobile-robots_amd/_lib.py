@@ -40,6 +40,11 @@ def load():
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} is missing: build it with __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # Load order matters in a process that also holds PyTorch: torch ships its own libamdhip64 (soname
+    # libamdhip64.so.7).  Importing torch first makes this library's DT_NEEDED libamdhip64.so.7 bind to that
+    # already-loaded runtime; the other order would put two HIP runtimes in one process and the second fails
+    # to initialise (hipGetDeviceCount -> error).
+    import torch  # noqa: F401
     L = C.CDLL(SO_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     cp = C.POINTER(CConfig)
