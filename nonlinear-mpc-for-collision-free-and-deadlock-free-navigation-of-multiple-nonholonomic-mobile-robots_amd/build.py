@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnmpc_hip.so")
-SOURCES = ["nmpc_kernels.hip", "nmpc_api.cpp"]
+SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_api.cpp"]
 DEPS = SOURCES + ["nmpc_device.h", os.path.join("..", "..", "include", "nmpc.h")]
 
 
@@ -30,6 +30,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + SOURCES
+    if os.environ.get("NMPC_PROFILE"):
+        cmd.insert(1, "-DNMPC_PROFILE")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -15,6 +15,8 @@ struct nmpc_handle {
     int32_t max_batch;
     double *ws;          // device workspace: max_batch * stride doubles
     int64_t ws_bytes;
+    int kernel;          // 2 = LDS-resident wave-per-instance kernel (default), 1 = HBM-resident workgroup kernel
+    long long *prof;     // device counters of the NMPC_PROFILE build (12 x int64), else unused
 };
 
 static bool m_supported(int m) { return (m >= 1 && m <= 6) || m == 8 || m == 10; }
@@ -86,8 +88,15 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     h->cfg = *cfg;
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
-    h->ws_bytes = (int64_t)sizeof(double) * h->P.stride * max_batch;
+    const char *kv = getenv("NMPC_KERNEL");
+    h->kernel = (kv && kv[0] == '1') ? 1 : 2;
+    nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
+    int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
+    h->ws_bytes = (int64_t)sizeof(double) * per * max_batch;
     if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
+    if (hipMalloc((void **)&h->prof, (12 + 24 * 2048) * sizeof(long long)) != hipSuccess) { (void)hipFree(h->ws); free(h); return NMPC_E_NOMEM; }
+    (void)hipMemset(h->prof, 0, (12 + 24 * 2048) * sizeof(long long));
+    { const char *ti = getenv("NMPC_TRACE_INST"); h->P.trace_inst = ti ? atoi(ti) : -1; }
     *out = h;
     return NMPC_OK;
 }
@@ -96,6 +105,7 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
 {
     if (!h) return NMPC_E_ARG;
     if (h->ws) (void)hipFree(h->ws);
+    if (h->prof) (void)hipFree(h->prof);
     free(h);
     return NMPC_OK;
 }
@@ -107,7 +117,9 @@ int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const dou
 {
     if (!h || !p || !w0 || !w_out || B < 0 || B > h->max_batch) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;
-    hipError_t e = nmpc::launch_solve(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream);
+    hipError_t e = (h->kernel == 1)
+                       ? nmpc::launch_solve(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
+                       : nmpc::launch_solve_lds(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
@@ -126,6 +138,42 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
     if (B == 0) return NMPC_OK;
     hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+/* development aid (not part of include/nmpc.h): per-phase cycle counters of an NMPC_PROFILE build */
+int32_t nmpc_debug_profile(nmpc_handle_t *h, int64_t *out12, int32_t reset)
+{
+    if (!h || !out12) return NMPC_E_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return NMPC_E_HIP;
+    if (hipMemcpy(out12, h->prof, 12 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
+    if (reset) (void)hipMemset(h->prof, 0, 12 * sizeof(long long));
+    return NMPC_OK;
+}
+int32_t nmpc_debug_trace(nmpc_handle_t *h, double *out, int32_t rows)
+{
+    if (!h || !out || rows > 2048) return NMPC_E_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return NMPC_E_HIP;
+    if (hipMemcpy(out, h->prof + 12, (size_t)rows * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
+    return NMPC_OK;
+}
+int32_t nmpc_debug_trace2(nmpc_handle_t *h, double *out, int32_t rows)
+{
+    if (!h || !out || rows > 2048) return NMPC_E_ARG;
+    if (hipMemcpy(out, h->prof + 12 + 16 * 2048, (size_t)rows * 8 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
+    return NMPC_OK;
+}
+
+/* development aid: copy the per-instance workspace of one instance to the host; returns its length in doubles */
+int64_t nmpc_debug_workspace(nmpc_handle_t *h, int32_t inst, double *out, int64_t cap, int64_t *offs)
+{
+    if (!h) return NMPC_E_ARG;
+    int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
+    if (offs) { offs[0] = h->kernel; offs[1] = h->P.oKG; offs[2] = h->P.oKFF; offs[3] = h->P.oPACK; offs[4] = h->P.oKT; }
+    if (!out) return per;
+    if (cap < per) return NMPC_E_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return NMPC_E_HIP;
+    if (hipMemcpy(out, h->ws + (size_t)inst * per, (size_t)per * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
+    return per;
 }
 
 const char *nmpc_version(void) { return "nmpc_hip 0.1 (gfx950, fp64, one workgroup per instance)"; }

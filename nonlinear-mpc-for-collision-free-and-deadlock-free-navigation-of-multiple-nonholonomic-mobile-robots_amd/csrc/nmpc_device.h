@@ -16,11 +16,17 @@ struct KParams {
     double obs[3 * NMPC_MAX_OBSTACLES];
     // per-instance workspace carve-up, in doubles
     int64_t stride;
+    int32_t trace_inst, pad_;   // NMPC_PROFILE builds: instance whose per-iteration trace is recorded
+    int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
+    int64_t oPACK, oKT;
     int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;
 };
 
 hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                         int32_t *iters, double *kkt, double *ws, hipStream_t st);
+hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
+void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);
 

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         }
 
         // ================= slack / dual steps, fraction to the boundary (IPOPT eq. 15)
-        double a_p = 1.0, a_d = 1.0;
+        double a_p = 1.0, a_d = 1.0, mult_max = 0.0;
         for (int k = 0; k <= N; k++) {
             const double *x = X + k * NX, *dxk = DX + k * NX, *duk = DU + (k < N ? k : 0) * NU;
             for (int s = tid; s < NH; s += TPB) {
@@ -650,6 +650,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 double ds = slot_jd<M_>(P, sPi, sPj, k, s, x, dxk, duk) + (H[e] - sv);
                 double dz = (mu - sv * zv - zv * ds) / sv;
                 DS[e] = ds; DZ[e] = dz;
+                if (s >= P.o_pr) mult_max = fmax(mult_max, fabs(zv + dz));
                 if (ds < 0.0) a_p = fmin(a_p, -tau * sv / ds);
                 if (dz < 0.0) a_d = fmin(a_d, -tau * zv / dz);
             }
@@ -718,8 +719,11 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             if (slot_active(P, k, s)) dphi -= mu * DS[e] / S[e];
         }
         dphi = blk_sum<TPB>(dphi, sRed);
+        for (int e = NX + tid; e < (N + 1) * NX; e += TPB) mult_max = fmax(mult_max, fabs(LAMN[e]));
+        mult_max = blk_max<TPB>(mult_max, sRed);
         if (th0 > 0.0) {
-            double nut = dphi / ((1.0 - 0.1) * th0);
+            // Nocedal-Wright (18.36), rho = 0.1; capped by the multiplier norm it cannot exceed in exact arithmetic
+            double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         const double D = dphi - nu_pen * th0;

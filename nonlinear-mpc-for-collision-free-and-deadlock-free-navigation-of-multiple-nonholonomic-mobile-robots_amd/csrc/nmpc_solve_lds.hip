@@ -1,0 +1,1028 @@
+// nmpc_solve_lds.hip — latency-oriented gfx950 solve kernel ("v2").
+//
+// The batch's wall time is set by the slowest instance (every instance is resident at once and
+// iteration counts have a long tail), so this kernel minimises the latency of ONE interior-point
+// iteration of ONE instance:
+//   * one wavefront (64 lanes) per swarm instance — every "barrier" is a wave-local LDS fence;
+//   * the whole iterate (X, U, lambda, step, all slacks and duals, sin/cos cache) lives in LDS for the
+//     entire solve;
+//   * everything of a stage that does not depend on the cost-to-go (gradients, barrier Hessian
+//     terms, the 3x2 Jacobian entries T cos, T sin, -T v sin, T v cos per robot) is computed for all
+//     stages in parallel ("stage packs", written to HBM/L2 and prefetched one stage ahead);
+//   * one Riccati stage = assemble the augmented symmetric matrix
+//         [ Quu Qux | qu ]      = [B A]^T P [B A] + H     (upper triangle + rhs column)
+//         [ Qxu Qxx | qx ]
+//     directly from P with the robot-sparse A,B (<= 3 terms per index), held in REGISTERS, one
+//     static set of elements per lane; NU pivot steps of symmetric elimination publish one pivot row
+//     per step through LDS; what remains in the registers is [P_k | p_k].  The feedback gains come
+//     from an in-register back substitution (one lane per column) and stream to HBM transposed;
+//   * forward sweep: gains prefetched a stage ahead, one LDS turnaround per stage;
+//   * multipliers: stage-parallel residual pass + robot-local adjoint recursion in registers.
+//
+// Reference blocks replaced: see nmpc_kernels.hip (same algorithm, same constants as the oracle).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "nmpc_device.h"
+
+namespace nmpc {
+
+template <int M_, int THB> struct G2 {
+    static constexpr int NX = 3 * M_, NU = 2 * M_, NP = M_ * (M_ - 1) / 2, NZ = NX + NU, LD = NZ + 1;
+    static constexpr int NXB = M_ * (2 + THB);
+    static constexpr int NT = NZ * (NZ + 1) / 2 + NZ;   // upper triangle + rhs column
+    // stage pack layout (doubles)
+    static constexpr int PK_G = 0;                 // [NZ]  rhs gradient  (u part then x part)
+    static constexpr int PK_HD = NZ;               // [NZ]  diagonal Hessian additions (without delta)
+    static constexpr int PK_HXY = 2 * NZ;          // [M]   (x_i,y_i) entry of robot i's diagonal block
+    static constexpr int PK_HVT = 2 * NZ + M_;     // [M]   (v_i,theta_i) cross term
+    static constexpr int PK_E = 2 * NZ + 2 * M_;   // [3 NP] NEGATED pair blocks -E_ij
+    static constexpr int PK_C = PK_E + 3 * (NP > 0 ? NP : 0);   // [NX]  defects c_k
+    static constexpr int PK_CF = PK_C + NX;        // [NZ][3] coefficients of the <=3 terms of each row/column of [B A]
+    static constexpr int PK_ZERO = PK_CF + 3 * NZ; // one zero entry (target of "no Hessian addition")
+    static constexpr int PACK = ((PK_ZERO + 1 + 7) / 8) * 8;
+    static constexpr int LDG = NZ + 1;             // row stride of G = P [B A | b-part]
+    static constexpr int KTS = ((NX + 1) * NU + 7) / 8 * 8;     // transposed gains per stage
+};
+
+// ---- single evaluation points.  Constraint values, slack steps and defects are recomputed at several places of an
+// iteration (Newton right-hand side, step-size rule, multiplier recursion, update).  With sigma = z/s up to 1e13 a
+// last-bit difference between two sites (e.g. a differently contracted a*b+c) shows up as 1e-7 in the dual residual, so
+// every site goes through these helpers, whose operation order is pinned with explicit fma().
+__device__ __forceinline__ double h_pair(double ex, double ey, double dmin2) { return fma(ex, ex, ey * ey) - dmin2; }
+__device__ __forceinline__ double ds_pair(double ex, double ey, double ddx, double ddy, double dmin2, double sv)
+{
+    return fma(2.0 * ex, ddx, (2.0 * ey) * ddy) + (h_pair(ex, ey, dmin2) - sv);
+}
+__device__ __forceinline__ double r_obs(double ex, double ey) { return sqrt(fma(ex, ex, ey * ey)); }
+__device__ __forceinline__ double h_obs(double rr, double robdim, double orad, double margin) { return rr - robdim - orad - margin; }
+__device__ __forceinline__ double ds_obs(double ex, double ey, double rr, double d0, double d1, double hv, double sv)
+{
+    return fma(ex, d0, ey * d1) / rr + (hv - sv);
+}
+__device__ __forceinline__ double defect_xy(double xn, double x, double tu, double cs) { return xn - fma(tu, cs, x); }   // tu = T*v
+__device__ __forceinline__ double defect_th(double xn, double x, double T, double w) { return xn - fma(T, w, x); }
+__device__ __forceinline__ double ds_bound(double jd, double hv, double sv) { return jd + (hv - sv); }
+__device__ __forceinline__ double dz_of(double mu, double sv, double zv, double ds) { return fma(-zv, ds, fma(-sv, zv, mu)) / sv; }
+
+template <int M_> __device__ __forceinline__ int pidx(int a, int b) { return a * (2 * M_ - a - 1) / 2 + (b - a - 1); }
+
+template <int TPB> __device__ __forceinline__ double wsum(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if constexpr (TPB > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; w++) t += red[w];
+        v = t;
+    }
+    return v;
+}
+template <int TPB> __device__ __forceinline__ double wmax(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    if constexpr (TPB > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = red[0];
+        for (int w = 1; w < TPB / 64; w++) t = fmax(t, red[w]);
+        v = t;
+    }
+    return v;
+}
+template <int TPB> __device__ __forceinline__ double wmin(double v, double *red) { return -wmax<TPB>(-v, red); }
+
+#ifdef NMPC_PROFILE
+#define PROF_T(i)                                                                                                                 \
+    do {                                                                                                                          \
+        long long _t = clock64();                                                                                                 \
+        prof[i] += _t - tlast;                                                                                                    \
+        tlast = _t;                                                                                                               \
+    } while (0)
+#else
+#define PROF_T(i) do { } while (0)
+#endif
+
+template <int M_, int THB, int TPB>
+__global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
+                                                         double *__restrict__ w_out, double *__restrict__ obj_out,
+                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
+                                                         double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
+{
+    using G = G2<M_, THB>;
+    constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB, NT = G::NT;
+    constexpr int NTP = (NT + TPB - 1) / TPB;
+    constexpr int HG = (TPB / NZ) > 0 ? (TPB / NZ) : 1;   // row groups of the G pass (thread -> column, rows strided)
+    constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
+    const int tid = threadIdx.x;
+    const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
+    const double T = P.T;
+    const size_t inst = blockIdx.x;
+
+    extern __shared__ double sm[];
+    double *X = sm;                       // [N1*NX]
+    double *U = X + N1 * NX;              // [N*NU]
+    double *LAM = U + N * NU;             // [N1*NX]   lam[k] pairs with defect c_{k-1}
+    double *DX = LAM + N1 * NX;           // [N1*NX]
+    double *DU = DX + N1 * NX;            // [N*NU]
+    double *RV = DU + N * NU;             // [N1*NX]   stage residuals of the adjoint recursion
+    double *SPp = RV + N1 * NX;           // [N1*NP]   pair slacks
+    double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
+    double *SO = ZPp + N1 * NP;           // [N1*MK]   obstacle slacks
+    double *ZO = SO + N1 * MK;            // [N1*MK]
+    double *ZUL = ZO + N1 * MK;           // [N*NU]
+    double *ZUU = ZUL + N * NU;           // [N*NU]
+    double *ZXL = ZUU + N * NU;           // [N1*NXB]
+    double *ZXU = ZXL + N1 * NXB;         // [N1*NXB]
+    double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds: s = u - lb computed on the fly
+    double *SUU = SUL + N * NU;           // [N*NU]    loses all relative accuracy once s ~ 1e-12 (active bound at mu = 1e-9)
+    double *SXL = SUU + N * NU;           // [N1*NXB]
+    double *SXU = SXL + N1 * NXB;         // [N1*NXB]
+    double *SN = SXU + N1 * NXB;          // [N*M]
+    double *CS = SN + N * M_;             // [N*M]
+    double *Pf = CS + N * M_;             // [NX*NX]   cost-to-go Hessian P (full symmetric storage)
+    double *PV = Pf + NX * NX;            // [NX]      cost-to-go gradient p
+    double *Gb = PV + NX;                 // [NX*LDG]  P [B A] and, in column NZ, p + P b
+    double *UR = Gb + NX * G::LDG;        // [NU*LD]   published pivot rows
+    double *PK = UR + NU * LD;            // [PACK]    current stage pack
+    double *PB = PK + G::PACK;            // [NX]
+    double *D0 = PB + NX;                 // [NU]   pivots as assembled
+    double *XS = D0 + NU;                 // [NX]
+    double *INV = XS + NX;                // [NU]   reciprocal pivots
+    double *RED = INV + NU;               // [8]
+
+    double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
+    double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    const double *pp = p_in + inst * (2 * NX);
+    const double *wi = w0 + inst * (size_t)P.nvar;
+    double *wo = w_out + inst * (size_t)P.nvar;
+
+#ifdef NMPC_PROFILE
+    long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
+
+    auto lbu = [&](int c) { return (c & 1) ? -P.wmax : -P.vmax; };
+    auto bst = [&](int s) { return THB ? s : 3 * (s >> 1) + (s & 1); };            // bounded-state slot -> state index
+    auto bvl = [&](int s) { return (THB && (s % 3 == 2)) ? P.thmax : P.xymax; };
+
+    // ---- static element ownership of the augmented matrix: e -> (row a, col c), c == NZ is the rhs column.
+    // Everything an element needs per stage is an LDS offset fixed for the whole solve (branch-free assembly):
+    //   value = sum_t CF[a][t] * G[ix(a,t)][c] + PK[hoff] + dl * delta
+    auto term_ix = [&](int a, int t) -> int {     // state index of term t of row/column a of [B A]
+        if (a < NU) { int i = a >> 1; return (a & 1) ? 3 * i + 2 : ((t == 1) ? 3 * i + 1 : 3 * i); }
+        int s = a - NU, i = s / 3, d = s - 3 * i;
+        return (d < 2) ? s : ((t == 0) ? s : (t == 1 ? 3 * i : 3 * i + 1));
+    };
+    int ea[NTP], ec[NTP], ga0[NTP], ga1[NTP], ga2[NTP], hoff[NTP], wa1[NTP], wa2[NTP];
+    double dl[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; t++) {
+        int e = tid + t * TPB, a = 0;
+        if (e < NT) {
+            while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
+            const int c = a + e;          // e in [0, NZ-a]: columns a..NZ
+            ea[t] = a; ec[t] = c;
+            ga0[t] = term_ix(a, 0) * G::LDG + c; ga1[t] = term_ix(a, 1) * G::LDG + c; ga2[t] = term_ix(a, 2) * G::LDG + c;
+            dl[t] = (c == a) ? 1.0 : 0.0;
+            int h = G::PK_ZERO;
+            if (c == NZ) h = G::PK_G + a;
+            else if (c == a) h = G::PK_HD + a;
+            else if (a < NU) { if (!(a & 1) && c == NU + 3 * (a >> 1) + 2) h = G::PK_HVT + (a >> 1); }
+            else {
+                int sa = a - NU, sc = c - NU, ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
+                if (da < 2 && dc < 2) h = (ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc);
+            }
+            hoff[t] = h;
+            if (a >= NU) {
+                if (c == NZ) { wa1[t] = NX * NX + (a - NU); wa2[t] = wa1[t]; }                  // PV follows Pf
+                else { wa1[t] = (a - NU) * NX + (c - NU); wa2[t] = (c - NU) * NX + (a - NU); }
+            } else { wa1[t] = 0; wa2[t] = 0; }
+        } else { ea[t] = -1; ec[t] = 0; ga0[t] = 0; ga1[t] = 0; ga2[t] = 0; hoff[t] = G::PK_ZERO; dl[t] = 0.0; wa1[t] = 0; wa2[t] = 0; }
+    }
+    // G pass: lane -> column gcol of [B A], rows grow0, grow0 + HG, ...
+    const int gcol = tid % NZ, grow0 = tid / NZ;
+    const bool gact = tid < HG * NZ;
+    const int gx0 = term_ix(gcol, 0), gx1 = term_ix(gcol, 1), gx2 = term_ix(gcol, 2);
+
+    // ---- load start, pin X_0, push into the interior of the simple bounds (IPOPT bound_push)
+    const double bp = 1e-2;
+    for (int c = tid; c < NX; c += TPB) XS[c] = pp[NX + c];
+    for (int e = tid; e < N1 * NX; e += TPB) {
+        int k = e / NX, c = e - k * NX;
+        double v = (k == 0) ? pp[c] : wi[e];
+        if (k >= 1) {
+            int d = c % 3;
+            if (d < 2 || THB) {
+                double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                v = fmin(fmax(v, -b + px), b - px);
+            }
+        }
+        X[e] = v; LAM[e] = 0.0;
+    }
+    for (int e = tid; e < N * NU; e += TPB) {
+        int c = e % NU;
+        double lo = lbu(c), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+        U[e] = fmin(fmax(wi[(size_t)N1 * NX + e], lo + pu), hi - pu);
+    }
+    __syncthreads();
+
+    // ---- stage-0 pair / obstacle rows act on the pinned state: feasibility pre-check
+    {
+        double bad = 0.0;
+        for (int q = tid; q < NP; q += TPB) {
+            int i = 0, r = q;
+            while (r >= M_ - 1 - i) { r -= M_ - 1 - i; i++; }
+            int j = i + 1 + r;
+            double dx = X[3 * i] - X[3 * j], dy = X[3 * i + 1] - X[3 * j + 1];
+            if (h_pair(dx, dy, P.dmin2) < 0.0) bad = 1.0;
+        }
+        for (int e = tid; e < MK; e += TPB) {
+            int i = e / K, o = e - i * K;
+            double dx = X[3 * i] - P.obs[3 * o], dy = X[3 * i + 1] - P.obs[3 * o + 1];
+            if (h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin) < 0.0) bad = 1.0;
+        }
+        bad = wmax<TPB>(bad, RED);
+        if (bad > 0.0) {
+            for (int e = tid; e < N1 * NX; e += TPB) wo[e] = X[e];
+            for (int e = tid; e < N * NU; e += TPB) wo[(size_t)N1 * NX + e] = U[e];
+            if (tid == 0) {
+                if (obj_out) obj_out[inst] = NAN;
+                if (status_out) status_out[inst] = NMPC_STATUS_INFEASIBLE_X0;
+                if (iters_out) iters_out[inst] = 0;
+                if (kkt_out) kkt_out[inst] = INFINITY;
+            }
+            return;
+        }
+    }
+
+    // pair (i,j) of flat index q
+    auto pair_ij = [&](int q, int &i, int &j) { i = 0; while (q >= M_ - 1 - i) { q -= M_ - 1 - i; i++; } j = i + 1 + q; };
+
+    // ---- trig cache of the current iterate
+    auto trig = [&]() {
+        for (int it = tid; it < N * M_; it += TPB) {
+            int k = it / M_, i = it - k * M_;
+            double s, c;
+            sincos(X[k * NX + 3 * i + 2], &s, &c);
+            SN[it] = s; CS[it] = c;
+        }
+    };
+    // ---- merit pieces at (X + a DX, U + a DU, S + a DS): objective, sum log s, l1 infeasibility, max defect / slack residual.
+    //      a == 0 evaluates the current point.  Every inequality row carries an explicit slack.
+    auto merit = [&](double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
+        double fs = 0.0, l = 0.0, t = 0.0, mc = 0.0, mh = 0.0;
+        // one bound row: current slack sv, current value h0, step of the value jd, trial value ht
+        auto brow = [&](double sv, double h0, double jd, double ht) {
+            double st = sv + a * (jd + (h0 - sv));
+            l += log(st);
+            double r = fabs(ht - st);
+            t += r; mh = fmax(mh, r);
+        };
+        for (int it = tid; it < N * M_; it += TPB) {
+            int k = it / M_, i = it - k * M_;
+            const int ox = k * NX + 3 * i, ou = k * NU + 2 * i;
+            double x0 = X[ox] + a * DX[ox], x1 = X[ox + 1] + a * DX[ox + 1], x2 = X[ox + 2] + a * DX[ox + 2];
+            double n0 = X[ox + NX] + a * DX[ox + NX], n1 = X[ox + NX + 1] + a * DX[ox + NX + 1], n2 = X[ox + NX + 2] + a * DX[ox + NX + 2];
+            double u0 = U[ou] + a * DU[ou], u1 = U[ou + 1] + a * DU[ou + 1];
+            double s, c;
+            if (a == 0.0) { s = SN[it]; c = CS[it]; } else sincos(x2, &s, &c);
+            double c0 = fabs(defect_xy(n0, x0, T * u0, c)), c1 = fabs(defect_xy(n1, x1, T * u0, s)), c2 = fabs(defect_th(n2, x2, T, u1));
+            t += c0 + c1 + c2; mc = fmax(mc, fmax(c0, fmax(c1, c2)));
+            double e0 = x0 - XS[3 * i], e1 = x1 - XS[3 * i + 1], e2 = x2 - XS[3 * i + 2];
+            fs += P.q[0] * e0 * e0 + P.q[1] * e1 * e1 + P.q[2] * e2 * e2 + P.r[0] * u0 * u0 + P.r[1] * u1 * u1;
+            // control bounds of stage k
+            brow(SUL[ou], U[ou] + P.vmax, DU[ou], u0 + P.vmax); brow(SUU[ou], P.vmax - U[ou], -DU[ou], P.vmax - u0);
+            brow(SUL[ou + 1], U[ou + 1] + P.wmax, DU[ou + 1], u1 + P.wmax); brow(SUU[ou + 1], P.wmax - U[ou + 1], -DU[ou + 1], P.wmax - u1);
+            // state bounds of stage k+1
+            const int sb = (k + 1) * NXB + (2 + THB) * i;
+            brow(SXL[sb], X[ox + NX] + P.xymax, DX[ox + NX], n0 + P.xymax); brow(SXU[sb], P.xymax - X[ox + NX], -DX[ox + NX], P.xymax - n0);
+            brow(SXL[sb + 1], X[ox + NX + 1] + P.xymax, DX[ox + NX + 1], n1 + P.xymax); brow(SXU[sb + 1], P.xymax - X[ox + NX + 1], -DX[ox + NX + 1], P.xymax - n1);
+            if (THB) { brow(SXL[sb + 2], X[ox + NX + 2] + P.thmax, DX[ox + NX + 2], n2 + P.thmax); brow(SXU[sb + 2], P.thmax - X[ox + NX + 2], -DX[ox + NX + 2], P.thmax - n2); }
+        }
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double dx = (X[oi] + a * DX[oi]) - (X[oj] + a * DX[oj]), dy = (X[oi + 1] + a * DX[oi + 1]) - (X[oj + 1] + a * DX[oj + 1]);
+            double h = h_pair(dx, dy, P.dmin2);
+            // trial slack: s + a ds, ds = J dx + (h0 - s)
+            double sv = SPp[k * NP + q];
+            if (a != 0.0) {
+                double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1];
+                sv += a * ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
+            }
+            l += log(sv);
+            double r = fabs(h - sv);
+            t += r; mh = fmax(mh, r);
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double px = X[oi] + a * DX[oi], py = X[oi + 1] + a * DX[oi + 1];
+            double h = h_obs(r_obs(px - P.obs[3 * o], py - P.obs[3 * o + 1]), P.robdim, P.obs[3 * o + 2], P.margin);
+            double sv = SO[k * MK + e];
+            if (a != 0.0) {
+                double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey);
+                sv += a * ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
+            }
+            l += log(sv);
+            double r = fabs(h - sv);
+            t += r; mh = fmax(mh, r);
+        }
+        fv = wsum<TPB>(fs, RED); lg = wsum<TPB>(l, RED); th = wsum<TPB>(t, RED);
+        ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
+    };
+
+    double mu = P.mu_init;
+    trig();
+    __syncthreads();
+    // ---- slacks and duals
+    for (int it = tid; it < N1 * NP; it += TPB) {
+        int k = it / NPd, q = it - k * NP;
+        if (k >= 1 && k <= N - 1) {
+            int i, j; pair_ij(q, i, j);
+            double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
+            double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
+            SPp[it] = sv; ZPp[it] = mu / sv;
+        } else { SPp[it] = 1.0; ZPp[it] = 0.0; }
+    }
+    for (int it = tid; it < N1 * MK; it += TPB) {
+        int k = it / MK, e = it - k * MK;
+        if (k >= 1 && k <= N - 1) {
+            int i = e / K, o = e - i * K;
+            double dx = X[k * NX + 3 * i] - P.obs[3 * o], dy = X[k * NX + 3 * i + 1] - P.obs[3 * o + 1];
+            double sv = fmax(h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin), bp);
+            SO[it] = sv; ZO[it] = mu / sv;
+        } else { SO[it] = 1.0; ZO[it] = 0.0; }
+    }
+    for (int e = tid; e < N * NU; e += TPB) {
+        int c = e % NU;
+        double lo = lbu(c);
+        double sl = fmax(U[e] - lo, 1e-12), su = fmax(-lo - U[e], 1e-12);
+        SUL[e] = sl; SUU[e] = su; ZUL[e] = mu / sl; ZUU[e] = mu / su;
+    }
+    for (int e = tid; e < N1 * NXB; e += TPB) {
+        int k = e / NXB, s = e - k * NXB;
+        if (k >= 1) {
+            double v = X[k * NX + bst(s)], b = bvl(s), sl = fmax(v + b, bp), su = fmax(b - v, bp);
+            SXL[e] = sl; SXU[e] = su; ZXL[e] = mu / sl; ZXU[e] = mu / su;
+        } else { SXL[e] = 1.0; SXU[e] = 1.0; ZXL[e] = 0.0; ZXU[e] = 0.0; }
+    }
+    __syncthreads();
+    double f, lgs, th0, e_c, e_h;
+    merit(0.0, f, lgs, th0, e_c, e_h);
+
+    double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    int iter = 0, status = NMPC_STATUS_MAX_ITER;
+    const double n_ineq = (double)P.n_ineq;
+    PROF_T(0);
+
+    for (;;) {
+        // ============ A. optimality error (IPOPT eq. 5): stationarity per (stage, robot), complementarity per slot
+        double e_d = 0.0, lsum = 0.0, zsum = 0.0, szmax = 0.0, szmin = INFINITY;
+#ifdef NMPC_PROFILE
+        double dbg_code = -1.0, dbg_v[4] = {0, 0, 0, 0};
+#endif
+        for (int it = tid; it < N * M_; it += TPB) {
+            int k = it / M_, i = it - k * M_, kk = k + 1;
+            const double *x = X + kk * NX;
+            double r0 = LAM[kk * NX + 3 * i], r1 = LAM[kk * NX + 3 * i + 1], r2 = LAM[kk * NX + 3 * i + 2];
+            lsum += fabs(r0) + fabs(r1) + fabs(r2);
+            if (kk < N) {
+                const double *ln = LAM + (kk + 1) * NX + 3 * i;
+                double v = U[kk * NU + 2 * i];
+                double a = -T * v * SN[kk * M_ + i], b = T * v * CS[kk * M_ + i];
+                r0 += 2 * P.q[0] * (x[3 * i] - XS[3 * i]) - ln[0];
+                r1 += 2 * P.q[1] * (x[3 * i + 1] - XS[3 * i + 1]) - ln[1];
+                r2 += 2 * P.q[2] * (x[3 * i + 2] - XS[3 * i + 2]) - (ln[2] + a * ln[0] + b * ln[1]);
+            }
+            // Jx^T z : bounds, pairs (ascending partner), obstacles
+            double j0, j1, j2 = 0.0;
+            {
+                const int sb = kk * NXB + (2 + THB) * i;
+                double zl0 = ZXL[sb], zu0 = ZXU[sb], zl1 = ZXL[sb + 1], zu1 = ZXU[sb + 1];
+                j0 = zl0 - zu0; j1 = zl1 - zu1;
+                zsum += zl0 + zu0 + zl1 + zu1;
+                double p0 = SXL[sb] * zl0, p1 = SXU[sb] * zu0, p2 = SXL[sb + 1] * zl1, p3 = SXU[sb + 1] * zu1;
+                szmax = fmax(szmax, fmax(fmax(p0, p1), fmax(p2, p3))); szmin = fmin(szmin, fmin(fmin(p0, p1), fmin(p2, p3)));
+                if (THB) {
+                    double zl2 = ZXL[sb + 2], zu2 = ZXU[sb + 2];
+                    j2 = zl2 - zu2; zsum += zl2 + zu2;
+                    double p4 = SXL[sb + 2] * zl2, p5 = SXU[sb + 2] * zu2;
+                    szmax = fmax(szmax, fmax(p4, p5)); szmin = fmin(szmin, fmin(p4, p5));
+                }
+            }
+            if (kk <= N - 1) {
+                const double xi = x[3 * i], yi = x[3 * i + 1];
+#pragma unroll 1
+                for (int j = 0; j < M_; j++) {
+                    if (j == i) continue;
+                    int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
+                    double z = ZPp[kk * NP + q];
+                    j0 += 2 * (xi - x[3 * j]) * z; j1 += 2 * (yi - x[3 * j + 1]) * z;
+                }
+                for (int o = 0; o < K; o++) {
+                    double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), z = ZO[kk * MK + i * K + o];
+                    j0 += dx / rr * z; j1 += dy / rr * z;
+                }
+            }
+#ifdef NMPC_PROFILE
+            { double m3 = fmax(fabs(r0 - j0), fmax(fabs(r1 - j1), fabs(r2 - j2)));
+              if (m3 > e_d) { dbg_code = 1000.0 * kk + 10.0 * i + (fabs(r0 - j0) == m3 ? 0 : (fabs(r1 - j1) == m3 ? 1 : 2)); dbg_v[0] = r0 - j0; dbg_v[1] = r1 - j1; dbg_v[2] = r2 - j2; dbg_v[3] = r2; } }
+#endif
+            e_d = fmax(e_d, fmax(fabs(r0 - j0), fmax(fabs(r1 - j1), fabs(r2 - j2))));
+            // control rows of stage k
+            const double *ln = LAM + (k + 1) * NX + 3 * i, *u = U + k * NU + 2 * i;
+            double c = CS[it], s = SN[it];
+            double zl0 = ZUL[k * NU + 2 * i], zu0 = ZUU[k * NU + 2 * i], zl1 = ZUL[k * NU + 2 * i + 1], zu1 = ZUU[k * NU + 2 * i + 1];
+            double rv = 2 * P.r[0] * u[0] - T * (c * ln[0] + s * ln[1]) - (zl0 - zu0);
+            double rw = 2 * P.r[1] * u[1] - T * ln[2] - (zl1 - zu1);
+#ifdef NMPC_PROFILE
+            if (fmax(fabs(rv), fabs(rw)) > e_d) { dbg_code = 1000.0 * k + 10.0 * i + (fabs(rv) > fabs(rw) ? 5 : 6); dbg_v[0] = rv; dbg_v[1] = rw; dbg_v[2] = zl0 - zu0; dbg_v[3] = zl1 - zu1; }
+#endif
+            e_d = fmax(e_d, fmax(fabs(rv), fabs(rw)));
+            zsum += zl0 + zu0 + zl1 + zu1;
+            double p0 = SUL[k * NU + 2 * i] * zl0, p1 = SUU[k * NU + 2 * i] * zu0, p2 = SUL[k * NU + 2 * i + 1] * zl1, p3 = SUU[k * NU + 2 * i + 1] * zu1;
+            szmax = fmax(szmax, fmax(fmax(p0, p1), fmax(p2, p3))); szmin = fmin(szmin, fmin(fmin(p0, p1), fmin(p2, p3)));
+        }
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            double zv = ZPp[NP + it], pz = SPp[NP + it] * zv;
+            zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            double zv = ZO[MK + it], pz = SO[MK + it] * zv;
+            zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
+        }
+#ifdef NMPC_PROFILE
+        { double my = e_d; double gm = wmax<TPB>(e_d, RED);
+          if (prof_out && (int)inst == P.trace_inst && iter < 2040 && my == gm) {
+              double *tr = reinterpret_cast<double *>(prof_out + 12 + 16 * 2048) + (size_t)iter * 8;
+              tr[0] = dbg_code; tr[1] = dbg_v[0]; tr[2] = dbg_v[1]; tr[3] = dbg_v[2]; tr[4] = dbg_v[3]; } }
+#endif
+        e_d = wmax<TPB>(e_d, RED); lsum = wsum<TPB>(lsum, RED); zsum = wsum<TPB>(zsum, RED);
+        szmax = wmax<TPB>(szmax, RED); szmin = wmin<TPB>(szmin, RED);
+        const double smax = 100.0;
+        double s_d = fmax(smax, (lsum + zsum) / ((double)(N * NX) + n_ineq)) / smax;
+        double s_c = fmax(smax, zsum / fmax(n_ineq, 1.0)) / smax;
+        double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
+        kkt = E0;
+        if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+        if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+        const double mu_min = P.tol / 10.0;
+        for (;;) {
+            double cm = fmax(fabs(szmax - mu), fabs(szmin - mu));
+            double Emu = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cm / s_c));
+            if (mu > mu_min && Emu <= 10.0 * mu) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
+            else break;
+        }
+        const double tau = fmax(0.99, 1.0 - mu);
+        PROF_T(1);
+
+        // ============ B0. stage packs: everything of stage k that does not depend on the cost-to-go
+        // (a) per (stage, robot): x-gradient, diagonal additions, cross terms, coefficients, defects
+        for (int it = tid; it < N1 * M_; it += TPB) {
+            int k = it / M_, i = it - k * M_;
+            const double *x = X + k * NX;
+            double *pk = gpack + (size_t)k * G::PACK;          // k == N: terminal block reuses the pack layout
+            double g0 = 0.0, g1 = 0.0, g2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0, hxy = 0.0;
+            if (k >= 1) {
+                if (k < N) {
+                    g0 = 2 * P.q[0] * (x[3 * i] - XS[3 * i]); g1 = 2 * P.q[1] * (x[3 * i + 1] - XS[3 * i + 1]); g2 = 2 * P.q[2] * (x[3 * i + 2] - XS[3 * i + 2]);
+                    h0 = 2 * P.q[0]; h1 = 2 * P.q[1]; h2 = 2 * P.q[2];
+                }
+                const int sb = k * NXB + (2 + THB) * i;
+                {   // bounds: v = mu/s - sigma (h - s), sigma = z/s, lower row gradient +1, upper row -1
+                    auto bv = [&](double sv, double zv, double hv, double &hd) { double sg = zv / sv; hd += sg; return mu / sv - sg * (hv - sv); };
+                    g0 -= bv(SXL[sb], ZXL[sb], x[3 * i] + P.xymax, h0) - bv(SXU[sb], ZXU[sb], P.xymax - x[3 * i], h0);
+                    g1 -= bv(SXL[sb + 1], ZXL[sb + 1], x[3 * i + 1] + P.xymax, h1) - bv(SXU[sb + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], h1);
+                    if (THB) g2 -= bv(SXL[sb + 2], ZXL[sb + 2], x[3 * i + 2] + P.thmax, h2) - bv(SXU[sb + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], h2);
+                }
+                if (k <= N - 1) {
+                    const double xi = x[3 * i], yi = x[3 * i + 1];
+#pragma unroll 1
+                    for (int j = 0; j < M_; j++) {
+                        if (j == i) continue;
+                        int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
+                        double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
+                        double sv = SPp[k * NP + q], zv = ZPp[k * NP + q], sg = zv / sv;
+                        double v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv);
+                        g0 -= 2 * dx * v; g1 -= 2 * dy * v;
+                        h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
+                    }
+                    for (int o = 0; o < K; o++) {
+                        double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = dx / rr, n1 = dy / rr;
+                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg = zv / sv, zz = zv / rr;
+                        double v = mu / sv - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv);
+                        g0 -= n0 * v; g1 -= n1 * v;
+                        h0 += sg * n0 * n0 - zz * (1 - n0 * n0); hxy += sg * n0 * n1 + zz * n0 * n1; h1 += sg * n1 * n1 - zz * (1 - n1 * n1);
+                    }
+                }
+            }
+            double hvt = 0.0;
+            if (k < N) {
+                const double *u = U + k * NU + 2 * i, *ln = LAM + (k + 1) * NX + 3 * i;
+                double c = CS[it], s = SN[it];
+                if (k >= 1) h2 += T * u[0] * (ln[0] * c + ln[1] * s);
+                hvt = T * (ln[0] * s - ln[1] * c);
+                // control gradient / diagonal
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const int eu = k * NU + 2 * i + d;
+                    double lo = d ? -P.wmax : -P.vmax, sl = SUL[eu], su = SUU[eu], zl = ZUL[eu], zu = ZUU[eu];
+                    double vl = mu / sl - zl / sl * ((u[d] - lo) - sl), vu = mu / su - zu / su * ((-lo - u[d]) - su);
+                    pk[G::PK_G + 2 * i + d] = 2 * P.r[d] * u[d] - (vl - vu);
+                    pk[G::PK_HD + 2 * i + d] = 2 * P.r[d] + zl / sl + zu / su;
+                }
+                {   // rows/columns of [B A] belonging to robot i: v_i, omega_i, x_i, y_i, theta_i
+                    double *cf = pk + G::PK_CF;
+                    cf[3 * (2 * i)] = T * c; cf[3 * (2 * i) + 1] = T * s; cf[3 * (2 * i) + 2] = 0.0;
+                    cf[3 * (2 * i + 1)] = T; cf[3 * (2 * i + 1) + 1] = 0.0; cf[3 * (2 * i + 1) + 2] = 0.0;
+                    cf[3 * (NU + 3 * i)] = 1.0; cf[3 * (NU + 3 * i) + 1] = 0.0; cf[3 * (NU + 3 * i) + 2] = 0.0;
+                    cf[3 * (NU + 3 * i + 1)] = 1.0; cf[3 * (NU + 3 * i + 1) + 1] = 0.0; cf[3 * (NU + 3 * i + 1) + 2] = 0.0;
+                    cf[3 * (NU + 3 * i + 2)] = 1.0; cf[3 * (NU + 3 * i + 2) + 1] = -T * u[0] * s; cf[3 * (NU + 3 * i + 2) + 2] = T * u[0] * c;
+                    if (i == 0) pk[G::PK_ZERO] = 0.0;
+                }
+                const double *xn = x + NX;
+                pk[G::PK_C + 3 * i] = defect_xy(xn[3 * i], x[3 * i], T * u[0], c);
+                pk[G::PK_C + 3 * i + 1] = defect_xy(xn[3 * i + 1], x[3 * i + 1], T * u[0], s);
+                pk[G::PK_C + 3 * i + 2] = defect_th(xn[3 * i + 2], x[3 * i + 2], T, u[1]);
+                pk[G::PK_HVT + i] = hvt;
+            }
+            pk[G::PK_G + NU + 3 * i] = g0; pk[G::PK_G + NU + 3 * i + 1] = g1; pk[G::PK_G + NU + 3 * i + 2] = g2;
+            pk[G::PK_HD + NU + 3 * i] = h0; pk[G::PK_HD + NU + 3 * i + 1] = h1; pk[G::PK_HD + NU + 3 * i + 2] = h2;
+            pk[G::PK_HXY + i] = hxy;
+        }
+        // (b) pair blocks E_ij = 4 sigma dp dp^T - 2 z I per (stage, pair)
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
+            double zz = ZPp[k * NP + q], sg = zz / SPp[k * NP + q];
+            double *pk = gpack + (size_t)k * G::PACK + G::PK_E + 3 * q;
+            pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
+        }
+        for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
+        __syncthreads();
+        PROF_T(2);
+
+        // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC)
+        double delta = 0.0;
+        bool ok;
+        for (;;) {
+            ok = true;
+            // terminal cost-to-go P_N = diag(hd_N) + delta, p_N = g_N
+            {
+                const double *pkN = gpack + (size_t)N * G::PACK;
+                for (int e = tid; e < NX * NX; e += TPB) {
+                    int r = e / NX, c = e - r * NX;
+                    Pf[e] = (r == c) ? (pkN[G::PK_HD + NU + r] + delta) : 0.0;
+                }
+                for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
+            }
+            // prefetch pack N-1 into registers
+            constexpr int PKR = (G::PACK + TPB - 1) / TPB;
+            double pkr[PKR];
+#pragma unroll
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            __syncthreads();
+            for (int k = N - 1; k >= 0; k--) {
+                // ---- stage pack -> LDS; prefetch the next one
+#pragma unroll
+                for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; if (e < G::PACK) PK[e] = pkr[t]; }
+                if (k > 0) {
+#pragma unroll
+                    for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
+                }
+                __syncthreads();
+                // ---- G = P [B A] (<= 3 terms per column, lane = column) and its last column p + P b, b = -c_k
+                if (gact) {
+                    const double c0 = PK[G::PK_CF + 3 * gcol], c1 = PK[G::PK_CF + 3 * gcol + 1], c2 = PK[G::PK_CF + 3 * gcol + 2];
+#pragma unroll 4
+                    for (int r = grow0; r < NX; r += HG)
+                        Gb[r * G::LDG + gcol] = c0 * Pf[r * NX + gx0] + c1 * Pf[r * NX + gx1] + c2 * Pf[r * NX + gx2];
+                }
+                for (int r = tid; r < NX; r += TPB) {
+                    double a = PV[r];
+#pragma unroll 6
+                    for (int c = 0; c < NX; c++) a -= Pf[r * NX + c] * PK[G::PK_C + c];
+                    Gb[r * G::LDG + NZ] = a;
+                }
+                __syncthreads();
+                // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
+                double mv[NTP];
+#pragma unroll
+                for (int t = 0; t < NTP; t++) {
+                    const int a = ea[t] < 0 ? 0 : ea[t];
+                    double v = PK[G::PK_CF + 3 * a] * Gb[ga0[t]] + PK[G::PK_CF + 3 * a + 1] * Gb[ga1[t]] + PK[G::PK_CF + 3 * a + 2] * Gb[ga2[t]];
+                    v += PK[hoff[t]] + dl[t] * delta;
+                    mv[t] = v;
+                    if (dl[t] != 0.0 && ea[t] >= 0 && ea[t] < NU) D0[ea[t]] = v;
+                }
+                // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
+                for (int j = 0; j < NU; j++) {
+#pragma unroll
+                    for (int t = 0; t < NTP; t++) if (ea[t] == j) UR[j * LD + ec[t]] = mv[t];
+                    __syncthreads();
+                    const double d = UR[j * LD + j];
+                    if (!(d > 1e-9 * fabs(D0[j])) || !(d > 0.0)) { ok = false; break; }
+                    const double inv = 1.0 / d;
+                    if (tid == 0) INV[j] = inv;
+#pragma unroll
+                    for (int t = 0; t < NTP; t++)
+                        if (ea[t] > j) mv[t] -= (UR[j * LD + ea[t]] * inv) * UR[j * LD + ec[t]];
+                }
+                if (!ok) break;
+                // ---- what is left is [P_k | p_k]: back to LDS (both triangles)
+                if (k >= 1) {
+#pragma unroll
+                    for (int t = 0; t < NTP; t++) if (ea[t] >= NU) { Pf[wa1[t]] = mv[t]; Pf[wa2[t]] = mv[t]; }
+                }
+                __syncthreads();
+                // ---- gains: one lane per column of [Qux | qu], back substitution in registers, stream out transposed
+                for (int col = tid; col <= NX; col += TPB) {
+                    double kc[NU];
+                    const int cc = (col < NX) ? NU + col : NZ;
+#pragma unroll
+                    for (int j = NU - 1; j >= 0; j--) {
+                        double acc = UR[j * LD + cc];
+#pragma unroll
+                        for (int c = j + 1; c < NU; c++) acc += UR[j * LD + c] * kc[c];
+                        kc[j] = -acc * INV[j];
+                    }
+                    double *kt = gkt + (size_t)k * G::KTS + col * NU;
+#pragma unroll
+                    for (int j = 0; j < NU; j++) kt[j] = kc[j];
+                }
+            }
+            if (ok) break;
+            __syncthreads();
+            if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
+            else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+            if (delta > 1e20) break;
+        }
+        if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+        if (delta > 0.0) delta_last = delta;
+        __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
+        PROF_T(3);
+
+        // ============ C. forward sweep; gains prefetched one stage ahead
+        {
+            for (int c = tid; c < NX; c += TPB) DX[c] = 0.0;
+            double kr[NX + 1], krn[NX + 1];
+            if (tid < NU) {
+#pragma unroll
+                for (int c = 0; c <= NX; c++) kr[c] = gkt[c * NU + tid];
+            }
+            __syncthreads();
+            for (int k = 0; k < N; k++) {
+                if (tid < NU && k + 1 < N) {
+#pragma unroll
+                    for (int c = 0; c <= NX; c++) krn[c] = gkt[(size_t)(k + 1) * G::KTS + c * NU + tid];
+                }
+                if (tid < NU) {
+                    double a = kr[NX];
+#pragma unroll
+                    for (int c = 0; c < NX; c++) a += kr[c] * DX[k * NX + c];
+                    DU[k * NU + tid] = a;
+                }
+                __syncthreads();
+                for (int i = tid; i < M_; i += TPB) {
+                    const double *x = X + k * NX + 3 * i, *xn = x + NX, *u = U + k * NU + 2 * i, *dx = DX + k * NX + 3 * i, *du = DU + k * NU + 2 * i;
+                    double s = SN[k * M_ + i], c = CS[k * M_ + i];
+                    double c0 = defect_xy(xn[0], x[0], T * u[0], c), c1 = defect_xy(xn[1], x[1], T * u[0], s), c2 = defect_th(xn[2], x[2], T, u[1]);
+                    double *dn = DX + (k + 1) * NX + 3 * i;
+                    dn[0] = dx[0] + (-T * u[0] * s) * dx[2] + T * c * du[0] - c0;
+                    dn[1] = dx[1] + (T * u[0] * c) * dx[2] + T * s * du[0] - c1;
+                    dn[2] = dx[2] + T * du[1] - c2;
+                }
+                __syncthreads();
+                if (tid < NU) {
+#pragma unroll
+                    for (int c = 0; c <= NX; c++) kr[c] = krn[c];
+                }
+            }
+        }
+        PROF_T(4);
+
+        // ============ D. fraction to the boundary (IPOPT eq. 15) over all inequality slots (ds, dz recomputed)
+        double a_p = 1.0, a_d = 1.0, mult_max = 0.0;   // mult_max: inf-norm of the QP multipliers of the rows that enter theta
+        auto fb = [&](double sv, double zv, double ds) -> double {
+            double dz = dz_of(mu, sv, zv, ds);
+            if (ds < 0.0) a_p = fmin(a_p, -tau * sv / ds);
+            if (dz < 0.0) a_d = fmin(a_d, -tau * zv / dz);
+            return zv + dz;
+        };
+        for (int e = tid; e < N * NU; e += TPB) {
+            int c = e % NU;
+            double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e];
+            fb(sl, ZUL[e], du + ((u - lo) - sl)); fb(su, ZUU[e], -du + ((-lo - u) - su));
+        }
+        for (int e = tid; e < N * NXB; e += TPB) {
+            int k = 1 + e / NXB, s = e - (k - 1) * NXB;
+            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = SXL[k * NXB + s], su = SXU[k * NXB + s];
+            fb(sl, ZXL[k * NXB + s], dv + ((v + b) - sl)); fb(su, ZXU[k * NXB + s], -dv + ((b - v) - su));
+        }
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q];
+            double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
+            mult_max = fmax(mult_max, fabs(fb(sv, ZPp[k * NP + q], ds)));
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e];
+            double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
+            mult_max = fmax(mult_max, fabs(fb(sv, ZO[k * MK + e], ds)));
+        }
+        a_p = wmin<TPB>(a_p, RED); a_d = wmin<TPB>(a_d, RED);
+        PROF_T(5);
+        // ============ F. multipliers of the QP: stage-parallel residuals, then the robot-local adjoint recursion in registers
+        //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k + delta dx_k) + Jx_k^T (z + dz)_k
+        for (int it = tid; it < N * M_; it += TPB) {
+            int k = 1 + it / M_, i = it - (k - 1) * M_;
+            const double *x = X + k * NX, *dx = DX + k * NX;
+            double l0, l1, l2 = 0.0;
+            {   // bounds: z + dz, dz = (mu - s z - z ds)/s, ds = +-dx + (h - s)
+                const int sb = k * NXB + (2 + THB) * i;
+                auto zn = [&](double sv, double zv, double hv, double jd) { double ds = jd + (hv - sv); return zv + dz_of(mu, sv, zv, ds); };
+                l0 = zn(SXL[sb], ZXL[sb], x[3 * i] + P.xymax, dx[3 * i]) - zn(SXU[sb], ZXU[sb], P.xymax - x[3 * i], -dx[3 * i]);
+                l1 = zn(SXL[sb + 1], ZXL[sb + 1], x[3 * i + 1] + P.xymax, dx[3 * i + 1]) - zn(SXU[sb + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], -dx[3 * i + 1]);
+                if (THB) l2 = zn(SXL[sb + 2], ZXL[sb + 2], x[3 * i + 2] + P.thmax, dx[3 * i + 2]) - zn(SXU[sb + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], -dx[3 * i + 2]);
+            }
+            l0 -= delta * dx[3 * i]; l1 -= delta * dx[3 * i + 1]; l2 -= delta * dx[3 * i + 2];
+            if (k < N) {
+                const double xi = x[3 * i], yi = x[3 * i + 1];
+#pragma unroll 1
+                for (int j = 0; j < M_; j++) {
+                    if (j == i) continue;
+                    int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
+                    double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
+                    double ddx = dx[3 * i] - dx[3 * j], ddy = dx[3 * i + 1] - dx[3 * j + 1];
+                    double sv = SPp[k * NP + q], zv = ZPp[k * NP + q];
+                    double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv);
+                    double znew = zv + dz_of(mu, sv, zv, ds);
+                    l0 += 2 * ex * znew + 2 * zv * ddx;      // Jx^T (z+dz)  -  (-2 z (ddx))  [exact-Hessian term of the pair row]
+                    l1 += 2 * ey * znew + 2 * zv * ddy;
+                }
+                for (int o = 0; o < K; o++) {
+                    double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = ex / rr, n1 = ey / rr;
+                    double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o];
+                    double nd = n0 * dx[3 * i] + n1 * dx[3 * i + 1];
+                    double ds = ds_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
+                    double znew = zv + dz_of(mu, sv, zv, ds), zz = zv / rr;
+                    l0 += n0 * znew + zz * (dx[3 * i] - n0 * nd);
+                    l1 += n1 * znew + zz * (dx[3 * i + 1] - n1 * nd);
+                }
+                l0 -= 2 * P.q[0] * (x[3 * i] - XS[3 * i]) + 2 * P.q[0] * dx[3 * i];
+                l1 -= 2 * P.q[1] * (x[3 * i + 1] - XS[3 * i + 1]) + 2 * P.q[1] * dx[3 * i + 1];
+                l2 -= 2 * P.q[2] * (x[3 * i + 2] - XS[3 * i + 2]) + 2 * P.q[2] * dx[3 * i + 2];
+                const double *ln = LAM + (k + 1) * NX + 3 * i;
+                double v = U[k * NU + 2 * i], c = CS[k * M_ + i], s = SN[k * M_ + i];
+                double htt = T * v * (ln[0] * c + ln[1] * s), hvt = T * (ln[0] * s - ln[1] * c);
+                l2 -= htt * dx[3 * i + 2] + hvt * DU[k * NU + 2 * i];
+            }
+            RV[k * NX + 3 * i] = l0; RV[k * NX + 3 * i + 1] = l1; RV[k * NX + 3 * i + 2] = l2;
+        }
+        __syncthreads();
+        for (int i = tid; i < M_; i += TPB) {
+            double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+            for (int k = N; k >= 1; k--) {
+                double l0 = RV[k * NX + 3 * i], l1 = RV[k * NX + 3 * i + 1], l2 = RV[k * NX + 3 * i + 2];
+                if (k < N) {
+                    double v = U[k * NU + 2 * i];
+                    double a = -T * v * SN[k * M_ + i], b = T * v * CS[k * M_ + i];
+                    l0 += n0; l1 += n1; l2 += n2 + a * n0 + b * n1;
+                }
+                n0 = l0; n1 = l1; n2 = l2;
+                RV[k * NX + 3 * i] = l0; RV[k * NX + 3 * i + 1] = l1; RV[k * NX + 3 * i + 2] = l2;     // lam+_k
+                mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
+            }
+        }
+        mult_max = wmax<TPB>(mult_max, RED);
+        __syncthreads();
+        PROF_T(7);
+
+
+        // ============ E. l1 merit backtracking line search; (f, sum log s, theta) of the current point are carried
+        double dphi = 0.0;
+        for (int it = tid; it < N1 * M_; it += TPB) {
+            int k = it / M_, i = it - k * M_;
+            if (k >= 1 && k < N) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) dphi += 2 * P.q[d] * (X[k * NX + 3 * i + d] - XS[3 * i + d]) * DX[k * NX + 3 * i + d];
+            }
+            if (k < N) {
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const int eu = k * NU + 2 * i + d;
+                    double u = U[eu], du = DU[eu], lo = d ? -P.wmax : -P.vmax, sl = SUL[eu], su = SUU[eu];
+                    dphi += 2 * P.r[d] * u * du - mu * ((du + ((u - lo) - sl)) / sl + (-du + ((-lo - u) - su)) / su);
+                }
+            }
+            if (k >= 1) {
+#pragma unroll
+                for (int d = 0; d < 2 + THB; d++) {
+                    const int sb = k * NXB + (2 + THB) * i + d;
+                    double v = X[k * NX + 3 * i + d], dv = DX[k * NX + 3 * i + d], b = (d == 2) ? P.thmax : P.xymax, sl = SXL[sb], su = SXU[sb];
+                    dphi -= mu * ((dv + ((v + b) - sl)) / sl + (-dv + ((b - v) - su)) / su);
+                }
+            }
+        }
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q];
+            double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
+            dphi -= mu * ds / sv;
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e];
+            double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
+            dphi -= mu * ds / sv;
+        }
+        dphi = wsum<TPB>(dphi, RED);
+        const double phi0 = f - mu * lgs;
+        if (th0 > 0.0) {
+            // Nocedal-Wright (18.36), rho = 0.1; capped by the multiplier norm it cannot exceed in exact arithmetic
+            double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
+            if (nu_pen < nut) nu_pen = nut + 1.0;
+        }
+        const double Dm = dphi - nu_pen * th0;
+        double alpha = a_p, ft, lgt, tht, ect, eht;
+        for (int ls = 0; ls < 30; ls++) {
+            merit(alpha, ft, lgt, tht, ect, eht);
+            if ((ft - mu * lgt) + nu_pen * tht <= phi0 + nu_pen * th0 + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
+            if (ls < 29) alpha *= 0.5;
+        }
+        PROF_T(6);
+#ifdef NMPC_PROFILE
+        if (prof_out && tid == 0 && (int)inst == P.trace_inst && iter < 2040) {
+            // linearised stationarity of the v-row of robot 0 at stage 0 with the QP multipliers (should be ~1e-14)
+            double u0 = U[0], du0 = DU[0], sl = SUL[0], su = SUU[0], zl = ZUL[0], zu = ZUU[0];
+            double dsl = du0 + ((u0 + P.vmax) - sl), dsu = -du0 + ((P.vmax - u0) - su);
+            double znl = zl + (mu - sl * zl - zl * dsl) / sl, znu = zu + (mu - su * zu - zu * dsu) / su;
+            double lin = 2 * P.r[0] * (u0 + du0) - T * (CS[0] * RV[NX] + SN[0] * RV[NX + 1]) - (znl - znu);
+            double *tr2 = reinterpret_cast<double *>(prof_out + 12 + 16 * 2048) + (size_t)iter * 8;
+            // Riccati-implied multiplier of stage 1, -(P_1 dx_1 + p_1), against the adjoint recursion (Pf/PV still hold P_1, p_1)
+            double dmax = 0.0, lr0 = 0.0;
+            for (int c = 0; c < NX; c++) {
+                double a = PV[c];
+                for (int j = 0; j < NX; j++) a += Pf[c * NX + j] * DX[NX + j];
+                double d = fabs(-a - RV[NX + c]);
+                if (d > dmax) dmax = d;
+                if (c == 0) lr0 = -a;
+            }
+            double lin2 = 2 * P.r[0] * (u0 + du0) - T * (CS[0] * lr0 + SN[0] * (-(PV[1] + [&]{ double a = 0; for (int j = 0; j < NX; j++) a += Pf[NX + j] * DX[NX + j]; return a; }()))) - (znl - znu);
+            tr2[5] = lin; tr2[6] = dmax; tr2[7] = lin2;
+        }
+        if (prof_out && tid == 0 && (int)inst == P.trace_inst && iter < 2040) {
+            double *tr = reinterpret_cast<double *>(prof_out + 12) + (size_t)iter * 16;
+            tr[0] = E0; tr[1] = e_d; tr[2] = e_c; tr[3] = e_h; tr[4] = szmax; tr[5] = mu; tr[6] = alpha; tr[7] = a_p; tr[8] = a_d;
+            tr[9] = delta; tr[10] = nu_pen; tr[11] = dphi; tr[12] = th0; tr[13] = f; tr[14] = s_d; tr[15] = mult_max;
+        }
+#endif
+
+        // ============ G. accept: duals first (they need the old primal point), then primal / slack step
+        auto zup = [&](double sv, double zv, double ds, double &snew) {
+            double dz = dz_of(mu, sv, zv, ds);
+            snew = sv + alpha * ds;
+            double z = zv + a_d * dz;
+            return fmin(fmax(z, mu / (1e10 * snew)), 1e10 * mu / snew);
+        };
+        for (int e = tid; e < N * NU; e += TPB) {
+            int c = e % NU;
+            double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e], sn;
+            ZUL[e] = zup(sl, ZUL[e], du + ((u - lo) - sl), sn); SUL[e] = sn;
+            ZUU[e] = zup(su, ZUU[e], -du + ((-lo - u) - su), sn); SUU[e] = sn;
+        }
+        for (int e = tid; e < N * NXB; e += TPB) {
+            int k = 1 + e / NXB, s = e - (k - 1) * NXB;
+            const int es = k * NXB + s;
+            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = SXL[es], su = SXU[es], sn;
+            ZXL[es] = zup(sl, ZXL[es], dv + ((v + b) - sl), sn); SXL[es] = sn;
+            ZXU[es] = zup(su, ZXU[es], -dv + ((b - v) - su), sn); SXU[es] = sn;
+        }
+        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q], sn;
+            double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
+            ZPp[k * NP + q] = zup(sv, ZPp[k * NP + q], ds, sn);
+            SPp[k * NP + q] = sn;
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e], sn;
+            double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
+            ZO[k * MK + e] = zup(sv, ZO[k * MK + e], ds, sn);
+            SO[k * MK + e] = sn;
+        }
+        __syncthreads();
+        for (int e = tid; e < N1 * NX; e += TPB) { X[e] += alpha * DX[e]; if (e >= NX) LAM[e] += alpha * (RV[e] - LAM[e]); }
+        for (int e = tid; e < N * NU; e += TPB) U[e] += alpha * DU[e];
+        __syncthreads();
+        trig();
+        __syncthreads();
+        f = ft; lgs = lgt; th0 = tht; e_c = ect; e_h = eht;
+        iter++;
+        PROF_T(8);
+    }
+
+    __syncthreads();
+    for (int e = tid; e < N1 * NX; e += TPB) wo[e] = X[e];
+    for (int e = tid; e < N * NU; e += TPB) wo[(size_t)N1 * NX + e] = U[e];
+    if (tid == 0) {
+        if (obj_out) obj_out[inst] = f;
+        if (status_out) status_out[inst] = status;
+        if (iters_out) iters_out[inst] = iter;
+        if (kkt_out) kkt_out[inst] = kkt;
+    }
+#ifdef NMPC_PROFILE
+    if (tid == 0 && prof_out) for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *)&prof_out[i], (unsigned long long)prof[i]);
+#endif
+}
+
+// LDS bytes of one instance
+template <int M_, int THB> static size_t lds_bytes(const KParams &P)
+{
+    using G = G2<M_, THB>;
+    const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
+    size_t d = N1 * G::NX * 4 + N * G::NU * 6 + N1 * G::NP * 2 + N1 * MK * 2 + N1 * G::NXB * 4 + N * M_ * 2 + (size_t)G::NX * G::NX + G::NX + (size_t)G::NX * G::LDG + (size_t)G::NU * G::LD +
+               G::PACK + G::NX * 2 + G::NU * 2 + 8;
+    return d * sizeof(double);
+}
+
+template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
+                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+{
+    // one wave per instance up to six robots; the augmented matrix of 8 / 10 robots (860 / 1325 elements) is spread over
+    // 2 / 4 waves so that the per-thread element tables stay in registers (64 threads spill to scratch there)
+    constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
+    size_t lds = lds_bytes<M_, THB>(P);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = solve_lds_kernel<M_, THB, TPB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(TPB), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
+    return hipGetLastError();
+}
+template <int M_> static hipError_t launch2_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                                              int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+{
+    return P.thb ? launch2_mt<M_, 1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st)
+                 : launch2_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+}
+
+hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+{
+    switch (m) {
+    case 1: return launch2_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 2: return launch2_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 3: return launch2_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 4: return launch2_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 5: return launch2_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 6: return launch2_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 8: return launch2_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 10: return launch2_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// workspace doubles per instance for this kernel (packs + transposed gains)
+void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride)
+{
+    const int thb = P.thb;
+    int64_t pack = 0, kts = 0;
+#define SZ(M)                                                                                                                     \
+    case M:                                                                                                                       \
+        pack = thb ? G2<M, 1>::PACK : G2<M, 0>::PACK;                                                                             \
+        kts = thb ? G2<M, 1>::KTS : G2<M, 0>::KTS;                                                                                \
+        break;
+    switch (m) { SZ(1) SZ(2) SZ(3) SZ(4) SZ(5) SZ(6) SZ(8) SZ(10) default: break; }
+#undef SZ
+    int64_t o = 0;
+    *pack_off = o; o += (int64_t)(P.N + 1) * pack; o = (o + 15) / 16 * 16;
+    *kt_off = o; o += (int64_t)P.N * kts; o = (o + 15) / 16 * 16;
+    *stride = o;
+}
+
+}  // namespace nmpc

@@ -27,6 +27,8 @@ class Opts:
     tau_min = 0.99
     bound_push = 1e-2
     exact_hessian = True
+    first_trial = 'zero'  # 'zero' (IPOPT: always try delta=0 first) or 'last' (start from delta_last/3 when the previous iteration needed delta>0)
+    reg_mode = 'global'   # 'global' (IPOPT alg. IC) or 'stage' (per-stage shift of Quu only)
     ls_max = 30
     eta = 1e-4
     verbose = False
@@ -148,6 +150,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
     delta_last = 0.0
     nu_pen = 1.0
     hist = []
+    sweeps_total = [0]
 
     def eval_all(X, U):
         C = np.zeros((N, nx)); Hx = []; Hu = []
@@ -245,8 +248,13 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
 
         # --- Riccati with inertia correction
         delta = 0.0
+        if o.first_trial == 'last' and delta_last > 0.0:
+            delta = delta_last / 3.0
+            if delta < 1e-9: delta = 0.0; delta_last = 0.0
         ntry = 0
+        nsweep = 0
         while True:
+            nsweep += 1
             ok = True
             P = Hxx[N] + delta * np.eye(nx); pv = gx[N].copy()
             Ks = [None] * N; ks = [None] * N
@@ -257,11 +265,25 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                 Quu = Huu[k] + delta * np.eye(nu) + B.T @ P @ B
                 Qux = Hux[k] + B.T @ P @ A
                 qu = gu[k] + B.T @ Pb
-                try:
+                if o.reg_mode == 'stage':
+                    dk = 0.0
+                    while True:
+                        try:
+                            Qt = Quu + dk * np.eye(nu)
+                            L = np.linalg.cholesky(Qt)
+                            if np.any(np.diag(L) ** 2 < 1e-9 * np.abs(np.diag(Qt))):
+                                raise np.linalg.LinAlgError
+                            break
+                        except np.linalg.LinAlgError:
+                            dk = 1e-4 if dk == 0.0 else dk * 10.0
+                            ntry += 1
+                    Quu = Qt
+                else:
+                  try:
                     L = np.linalg.cholesky(Quu)
                     if np.any(np.diag(L) ** 2 < 1e-9 * np.abs(np.diag(Quu))):
                         raise np.linalg.LinAlgError
-                except np.linalg.LinAlgError:
+                  except np.linalg.LinAlgError:
                     ok = False; break
                 Kk = -np.linalg.solve(Quu, Qux); kk = -np.linalg.solve(Quu, qu)
                 Ks[k], ks[k] = Kk, kk
@@ -283,6 +305,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             status = 2; break
         if delta > 0:
             delta_last = delta
+        sweeps_total[0] += nsweep
         # forward
         dX = np.zeros((N + 1, nx)); dU = np.zeros((N, nu))
         for k in range(N):
@@ -363,4 +386,4 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
 
     wout = np.concatenate([X.reshape(-1), U.reshape(-1)])
     fval = float(np.sum(qd * (X[:N] - xs) ** 2) + np.sum(rd * U * U))
-    return dict(x=wout, f=fval, status=status, iters=it, kkt=kkt, lam=lam, hist=hist)
+    return dict(x=wout, f=fval, status=status, iters=it, kkt=kkt, lam=lam, hist=hist, sweeps=sweeps_total[0])

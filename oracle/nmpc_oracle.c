@@ -565,7 +565,8 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             }
         }
         /* ---- slack / dual steps and fraction to the boundary (IPOPT eq. 15) */
-        double a_p = 1.0, a_d = 1.0;
+        double a_p = 1.0, a_d = 1.0, mult_max = 0.0;   /* mult_max: inf-norm of the QP multipliers of all rows that enter theta */
+        for (size_t i = nx; i < (size_t)(N + 1) * nx; i++) mult_max = fmax(mult_max, fabs(w->lamn[i]));
         for (int k = 0; k <= N; k++) {
             j_apply(w, k, w->X + (size_t)k * nx, w->dX + (size_t)k * nx, k < N ? w->dU + (size_t)k * nu : NULL, Jd);
             for (int s = 0; s < nh; s++) {
@@ -574,6 +575,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 double ds = Jd[s] + (w->H[o] - w->S[o]);
                 double dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o];
                 w->dS[o] = ds; w->dZ[o] = dz;
+                if (s >= w->o_pr) mult_max = fmax(mult_max, fabs(w->Z[o] + dz));
                 if (ds < 0.0) a_p = fmin(a_p, -tau * w->S[o] / ds);
                 if (dz < 0.0) a_d = fmin(a_d, -tau * w->Z[o] / dz);
             }
@@ -588,7 +590,9 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             for (int s = 0; s < nh; s++) if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; dphi -= mu * w->dS[o] / w->S[o]; }
         }
         if (th0 > 0.0) {
-            double nut = dphi / ((1.0 - 0.1) * th0);
+            /* Nocedal-Wright (18.36) with rho = 0.1.  In exact arithmetic dphi <= ||multipliers+||_inf * theta, so the
+               quotient never exceeds mult_max / 0.9; the cap only filters the case theta ~ rounding noise. */
+            double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         double D = dphi - nu_pen * th0, alpha = a_p, ft = f;

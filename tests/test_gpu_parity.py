@@ -55,7 +55,7 @@ def test_solve_matches_oracle(built, name, ocfg, B, idx):
     assert (rel[same] <= F_RTOL).all()
     # instances that ended in another basin must still be KKT points (independent check)
     for b in np.where(~same)[0][:4]:
-        k = R.kkt_report(ocfg, r["x"][b], P[b])
+        k = R.kkt_report(ocfg, r["x"][b], P[b], tol_active=1e-3)
         assert k["stat"] < 1e-5 and k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
     # x0 is pinned and bounds hold exactly
     assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
@@ -89,7 +89,7 @@ def test_literal_scenarios(built):
         s = _solver(ocfg, 1, max_iter=600)
         r = _np(s.solve_batch(p, w0)); torch.cuda.synchronize()
         assert r["status"][0] == 0, (r["status"], r["iters"], r["kkt"])
-        k = R.kkt_report(ocfg, r["x"][0], p[0])
+        k = R.kkt_report(ocfg, r["x"][0], p[0], tol_active=1e-3)
         assert k["stat"] < 1e-5 and k["eq"] < 1e-7 and k["ineq"] < 1e-7, k
 
 
