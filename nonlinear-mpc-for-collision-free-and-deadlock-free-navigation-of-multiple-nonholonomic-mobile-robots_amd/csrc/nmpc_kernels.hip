@@ -420,7 +420,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             // terminal: P_N = Hxx_N + delta I (bound barrier terms only), p_N = gx_N
             for (int e = tid; e < NX * NX; e += TPB) sP[e] = 0.0;
             __syncthreads();
-            for (int c = tid; c < NX; c += TPB) { sP[c * NX + c] = delta; sPv[c] = GX[N * NX + c]; }
+            for (int c = tid; c < NX; c += TPB) sPv[c] = GX[N * NX + c];   // the inertia shift acts on the controls only
             __syncthreads();
             for (int s = tid; s < P.nxb; s += TPB) {
                 int c = bnd_state(P, s);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 if (k >= 1) {
                     for (int c = tid; c < NX; c += TPB) {
                         int i = c / 3, d = c - 3 * i;
-                        double add = delta + ((k < N) ? 2 * P.q[d] : 0.0);
+                        double add = (k < N) ? 2 * P.q[d] : 0.0;
                         if (d == 2) add += HTT[k * M_ + i];
                         sP[c * NX + c] += add;
                         sQx[c] += GX[k * NX + c];
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 const double *zk = Z + k * NH, *dzk = DZ + k * NH;
                 double j0, j1, j2;
                 jxT_robot<M_>(P, k, i, x, [&](int s) { return zk[s] + dzk[s]; }, j0, j1, j2);
-                double l0 = j0 - delta * dx[3 * i], l1 = j1 - delta * dx[3 * i + 1], l2 = j2 - delta * dx[3 * i + 2];
+                double l0 = j0, l1 = j1, l2 = j2;
                 if (k < N) {
                     l0 -= 2 * P.q[0] * (x[3 * i] - sXs[3 * i]) + 2 * P.q[0] * dx[3 * i];
                     l1 -= 2 * P.q[1] * (x[3 * i + 1] - sXs[3 * i + 1]) + 2 * P.q[1] * dx[3 * i + 1];
@@ -724,6 +724,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         if (th0 > 0.0) {
             // Nocedal-Wright (18.36), rho = 0.1; capped by the multiplier norm it cannot exceed in exact arithmetic
             double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
+            nu_pen = fmax(1.0, 0.5 * nu_pen);
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         const double D = dphi - nu_pen * th0;

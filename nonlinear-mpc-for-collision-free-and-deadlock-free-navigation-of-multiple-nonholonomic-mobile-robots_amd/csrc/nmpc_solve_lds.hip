@@ -24,6 +24,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "nmpc_device.h"
 
 namespace nmpc {
@@ -43,6 +45,11 @@ template <int M_, int THB> struct G2 {
     static constexpr int PK_ZERO = PK_CF + 3 * NZ; // one zero entry (target of "no Hessian addition")
     static constexpr int PACK = ((PK_ZERO + 1 + 7) / 8) * 8;
     static constexpr int LDG = NZ + 1;             // row stride of G = P [B A | b-part]
+    // element e of the row-major upper triangle (+ rhs column) lives in row row_of(e); thread tid owns e = tid + t*TPB, so
+    // "slice" t holds rows slice_lo(t)..slice_hi(t): compile-time knowledge of which slices a pivot step touches
+    static constexpr int row_of(int e) { int a = 0; while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; } return a; }
+    static constexpr int slice_lo(int t, int tpb) { return row_of(t * tpb); }
+    static constexpr int slice_hi(int t, int tpb) { return row_of((t * tpb + tpb - 1 < NT) ? (t * tpb + tpb - 1) : (NT - 1)); }
     static constexpr int KTS = ((NX + 1) * NU + 7) / 8 * 8;     // transposed gains per stage
 };
 
@@ -65,6 +72,24 @@ __device__ __forceinline__ double defect_xy(double xn, double x, double tu, doub
 __device__ __forceinline__ double defect_th(double xn, double x, double T, double w) { return xn - fma(T, w, x); }
 __device__ __forceinline__ double ds_bound(double jd, double hv, double sv) { return jd + (hv - sv); }
 __device__ __forceinline__ double dz_of(double mu, double sv, double zv, double ds) { return fma(-zv, ds, fma(-sv, zv, mu)) / sv; }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (indices usable in `if constexpr`)
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// reciprocal: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, a third of the cost of an IEEE division chain)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 
 template <int M_> __device__ __forceinline__ int pidx(int a, int b) { return a * (2 * M_ - a - 1) / 2 + (b - a - 1); }
 
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         int s = a - NU, i = s / 3, d = s - 3 * i;
         return (d < 2) ? s : ((t == 0) ? s : (t == 1 ? 3 * i : 3 * i + 1));
     };
-    int ea[NTP], ec[NTP], ga0[NTP], ga1[NTP], ga2[NTP], hoff[NTP], wa1[NTP], wa2[NTP];
+    int ea[NTP], eac[NTP], ec[NTP], ga0[NTP], ga1[NTP], ga2[NTP], hoff[NTP], wa1[NTP], wa2[NTP];
     double dl[NTP];
 #pragma unroll
     for (int t = 0; t < NTP; t++) {
@@ -188,9 +213,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         if (e < NT) {
             while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
             const int c = a + e;          // e in [0, NZ-a]: columns a..NZ
-            ea[t] = a; ec[t] = c;
+            ea[t] = a; eac[t] = a; ec[t] = c;
             ga0[t] = term_ix(a, 0) * G::LDG + c; ga1[t] = term_ix(a, 1) * G::LDG + c; ga2[t] = term_ix(a, 2) * G::LDG + c;
-            dl[t] = (c == a) ? 1.0 : 0.0;
+            dl[t] = (c == a && a < NU) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
             int h = G::PK_ZERO;
             if (c == NZ) h = G::PK_G + a;
             else if (c == a) h = G::PK_HD + a;
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 if (c == NZ) { wa1[t] = NX * NX + (a - NU); wa2[t] = wa1[t]; }                  // PV follows Pf
                 else { wa1[t] = (a - NU) * NX + (c - NU); wa2[t] = (c - NU) * NX + (a - NU); }
             } else { wa1[t] = 0; wa2[t] = 0; }
-        } else { ea[t] = -1; ec[t] = 0; ga0[t] = 0; ga1[t] = 0; ga2[t] = 0; hoff[t] = G::PK_ZERO; dl[t] = 0.0; wa1[t] = 0; wa2[t] = 0; }
+        } else { ea[t] = -1; eac[t] = 0; ec[t] = 0; ga0[t] = 0; ga1[t] = 0; ga2[t] = 0; hoff[t] = G::PK_ZERO; dl[t] = 0.0; wa1[t] = 0; wa2[t] = 0; }
     }
     // G pass: lane -> column gcol of [B A], rows grow0, grow0 + HG, ...
     const int gcol = tid % NZ, grow0 = tid / NZ;
@@ -578,12 +603,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         bool ok;
         for (;;) {
             ok = true;
-            // terminal cost-to-go P_N = diag(hd_N) + delta, p_N = g_N
+            // terminal cost-to-go P_N = diag(hd_N), p_N = g_N
             {
                 const double *pkN = gpack + (size_t)N * G::PACK;
                 for (int e = tid; e < NX * NX; e += TPB) {
                     int r = e / NX, c = e - r * NX;
-                    Pf[e] = (r == c) ? (pkN[G::PK_HD + NU + r] + delta) : 0.0;
+                    Pf[e] = (r == c) ? pkN[G::PK_HD + NU + r] : 0.0;
                 }
                 for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
             }
@@ -616,6 +641,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     Gb[r * G::LDG + NZ] = a;
                 }
                 __syncthreads();
+                PROF_T(9);
                 // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
                 double mv[NTP];
 #pragma unroll
@@ -624,21 +650,36 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     double v = PK[G::PK_CF + 3 * a] * Gb[ga0[t]] + PK[G::PK_CF + 3 * a + 1] * Gb[ga1[t]] + PK[G::PK_CF + 3 * a + 2] * Gb[ga2[t]];
                     v += PK[hoff[t]] + dl[t] * delta;
                     mv[t] = v;
-                    if (dl[t] != 0.0 && ea[t] >= 0 && ea[t] < NU) D0[ea[t]] = v;
+                    if (dl[t] != 0.0) D0[ea[t]] = v;
                 }
+                PROF_T(10);
                 // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
-                for (int j = 0; j < NU; j++) {
-#pragma unroll
-                    for (int t = 0; t < NTP; t++) if (ea[t] == j) UR[j * LD + ec[t]] = mv[t];
-                    __syncthreads();
-                    const double d = UR[j * LD + j];
-                    if (!(d > 1e-9 * fabs(D0[j])) || !(d > 0.0)) { ok = false; break; }
-                    const double inv = 1.0 / d;
-                    if (tid == 0) INV[j] = inv;
-#pragma unroll
-                    for (int t = 0; t < NTP; t++)
-                        if (ea[t] > j) mv[t] -= (UR[j * LD + ea[t]] * inv) * UR[j * LD + ec[t]];
-                }
+                static_for<0, NU>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (ok) {
+                        // publish pivot row j: only the (at most two) slices that hold it
+                        static_for<0, NTP>([&](auto tc) {
+                            constexpr int t = decltype(tc)::value;
+                            if constexpr (G::slice_lo(t, TPB) <= j && j <= G::slice_hi(t, TPB)) { if (ea[t] == j) UR[j * LD + ec[t]] = mv[t]; }
+                        });
+                        __syncthreads();
+                        const double d = UR[j * LD + j];
+                        if (!(d > 1e-9 * fabs(D0[j])) || !(d > 0.0)) ok = false;
+                        else {
+                            const double inv = rcp_nr(d);
+                            if (tid == 0) INV[j] = inv;
+                            // rank-1 update of every live slice, branch-free (all LDS reads of the step issue back to back)
+                            static_for<0, NTP>([&](auto tc) {
+                                constexpr int t = decltype(tc)::value;
+                                if constexpr (G::slice_hi(t, TPB) > j) {
+                                    const double upd = (UR[j * LD + eac[t]] * inv) * UR[j * LD + ec[t]];
+                                    mv[t] = (ea[t] > j) ? (mv[t] - upd) : mv[t];
+                                }
+                            });
+                        }
+                    }
+                });
+                PROF_T(11);
                 if (!ok) break;
                 // ---- what is left is [P_k | p_k]: back to LDS (both triangles)
                 if (k >= 1) {
@@ -673,42 +714,48 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
         PROF_T(3);
 
-        // ============ C. forward sweep; gains prefetched one stage ahead
+        // ============ C. forward sweep.  Gains stream back from HBM/L2 through a register ring filled PD stages ahead by
+        // all threads (coalesced), then through an LDS staging buffer (Gb is free here) from which the control lanes read.
         {
-            for (int c = tid; c < NX; c += TPB) DX[c] = 0.0;
-            double kr[NX + 1], krn[NX + 1];
-            if (tid < NU) {
+            constexpr int KPT = (G::KTS + TPB - 1) / TPB, PD = 4;
+            double kq[PD][KPT];
 #pragma unroll
-                for (int c = 0; c <= NX; c++) kr[c] = gkt[c * NU + tid];
+            for (int d = 0; d < PD; d++)
+#pragma unroll
+                for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; kq[d][t] = (d < N && e < G::KTS) ? gkt[(size_t)d * G::KTS + e] : 0.0; }
+            for (int c = tid; c < NX; c += TPB) DX[c] = 0.0;
+            for (int k0 = 0; k0 < N; k0 += PD) {
+#pragma unroll
+                for (int d = 0; d < PD; d++) {
+                    const int k = k0 + d;
+                    if (k < N) {
+#pragma unroll
+                        for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) Gb[e] = kq[d][t]; }
+                        if (k + PD < N) {
+#pragma unroll
+                            for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) kq[d][t] = gkt[(size_t)(k + PD) * G::KTS + e]; }
+                        }
+                        __syncthreads();
+                        if (tid < NU) {
+                            double a = Gb[NX * NU + tid];
+#pragma unroll
+                            for (int c = 0; c < NX; c++) a += Gb[c * NU + tid] * DX[k * NX + c];
+                            DU[k * NU + tid] = a;
+                        }
+                        __syncthreads();
+                        for (int i = tid; i < M_; i += TPB) {
+                            const double *x = X + k * NX + 3 * i, *xn = x + NX, *u = U + k * NU + 2 * i, *dx = DX + k * NX + 3 * i, *du = DU + k * NU + 2 * i;
+                            double s = SN[k * M_ + i], c = CS[k * M_ + i];
+                            double c0 = defect_xy(xn[0], x[0], T * u[0], c), c1 = defect_xy(xn[1], x[1], T * u[0], s), c2 = defect_th(xn[2], x[2], T, u[1]);
+                            double *dn = DX + (k + 1) * NX + 3 * i;
+                            dn[0] = dx[0] + (-T * u[0] * s) * dx[2] + T * c * du[0] - c0;
+                            dn[1] = dx[1] + (T * u[0] * c) * dx[2] + T * s * du[0] - c1;
+                            dn[2] = dx[2] + T * du[1] - c2;
+                        }
+                    }
+                }
             }
             __syncthreads();
-            for (int k = 0; k < N; k++) {
-                if (tid < NU && k + 1 < N) {
-#pragma unroll
-                    for (int c = 0; c <= NX; c++) krn[c] = gkt[(size_t)(k + 1) * G::KTS + c * NU + tid];
-                }
-                if (tid < NU) {
-                    double a = kr[NX];
-#pragma unroll
-                    for (int c = 0; c < NX; c++) a += kr[c] * DX[k * NX + c];
-                    DU[k * NU + tid] = a;
-                }
-                __syncthreads();
-                for (int i = tid; i < M_; i += TPB) {
-                    const double *x = X + k * NX + 3 * i, *xn = x + NX, *u = U + k * NU + 2 * i, *dx = DX + k * NX + 3 * i, *du = DU + k * NU + 2 * i;
-                    double s = SN[k * M_ + i], c = CS[k * M_ + i];
-                    double c0 = defect_xy(xn[0], x[0], T * u[0], c), c1 = defect_xy(xn[1], x[1], T * u[0], s), c2 = defect_th(xn[2], x[2], T, u[1]);
-                    double *dn = DX + (k + 1) * NX + 3 * i;
-                    dn[0] = dx[0] + (-T * u[0] * s) * dx[2] + T * c * du[0] - c0;
-                    dn[1] = dx[1] + (T * u[0] * c) * dx[2] + T * s * du[0] - c1;
-                    dn[2] = dx[2] + T * du[1] - c2;
-                }
-                __syncthreads();
-                if (tid < NU) {
-#pragma unroll
-                    for (int c = 0; c <= NX; c++) kr[c] = krn[c];
-                }
-            }
         }
         PROF_T(4);
 
@@ -748,7 +795,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         a_p = wmin<TPB>(a_p, RED); a_d = wmin<TPB>(a_d, RED);
         PROF_T(5);
         // ============ F. multipliers of the QP: stage-parallel residuals, then the robot-local adjoint recursion in registers
-        //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k + delta dx_k) + Jx_k^T (z + dz)_k
+        //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k) + Jx_k^T (z + dz)_k
         for (int it = tid; it < N * M_; it += TPB) {
             int k = 1 + it / M_, i = it - (k - 1) * M_;
             const double *x = X + k * NX, *dx = DX + k * NX;
@@ -760,7 +807,6 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 l1 = zn(SXL[sb + 1], ZXL[sb + 1], x[3 * i + 1] + P.xymax, dx[3 * i + 1]) - zn(SXU[sb + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], -dx[3 * i + 1]);
                 if (THB) l2 = zn(SXL[sb + 2], ZXL[sb + 2], x[3 * i + 2] + P.thmax, dx[3 * i + 2]) - zn(SXU[sb + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], -dx[3 * i + 2]);
             }
-            l0 -= delta * dx[3 * i]; l1 -= delta * dx[3 * i + 1]; l2 -= delta * dx[3 * i + 2];
             if (k < N) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
 #pragma unroll 1
@@ -859,6 +905,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         if (th0 > 0.0) {
             // Nocedal-Wright (18.36), rho = 0.1; capped by the multiplier norm it cannot exceed in exact arithmetic
             double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
+            nu_pen = fmax(1.0, 0.5 * nu_pen);      // the penalty may relax again: one bad step must not cripple the rest of the solve
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         const double Dm = dphi - nu_pen * th0;

@@ -27,6 +27,7 @@ class Opts:
     tau_min = 0.99
     bound_push = 1e-2
     exact_hessian = True
+    reg_where = 'u'       # 'all': delta*I on x and u (IPOPT); 'u': controls only; 'thu': headings and controls
     first_trial = 'zero'  # 'zero' (IPOPT: always try delta=0 first) or 'last' (start from delta_last/3 when the previous iteration needed delta>0)
     reg_mode = 'global'   # 'global' (IPOPT alg. IC) or 'stage' (per-stage shift of Quu only)
     ls_max = 30
@@ -256,7 +257,10 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         while True:
             nsweep += 1
             ok = True
-            P = Hxx[N] + delta * np.eye(nx); pv = gx[N].copy()
+            if o.reg_where == 'all': Dx = delta * np.eye(nx)
+            elif o.reg_where == 'u': Dx = np.zeros((nx, nx))
+            else: Dx = delta * np.diag(np.tile([0.0, 0.0, 1.0], cfg.m))
+            P = Hxx[N] + Dx; pv = gx[N].copy()
             Ks = [None] * N; ks = [None] * N
             for k in range(N - 1, -1, -1):
                 A, B = AB[k]
@@ -288,7 +292,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                 Kk = -np.linalg.solve(Quu, Qux); kk = -np.linalg.solve(Quu, qu)
                 Ks[k], ks[k] = Kk, kk
                 if k >= 1:
-                    Qxx = Hxx[k] + delta * np.eye(nx) + A.T @ P @ A
+                    Qxx = Hxx[k] + Dx + A.T @ P @ A
                     qx = gx[k] + A.T @ Pb
                     P = Qxx + Qux.T @ Kk; P = 0.5 * (P + P.T)
                     pv = qx + Qux.T @ kk
@@ -313,9 +317,9 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             dX[k + 1] = AB[k][0] @ dX[k] + AB[k][1] @ dU[k] - C[k]
         # multipliers of the QP (= lam + dlam), matrix-free backward recursion
         lamn = np.zeros_like(lam)
-        lamn[N] = -((Hxx[N] + delta * np.eye(nx)) @ dX[N] + gx[N])
+        lamn[N] = -((Hxx[N] + Dx) @ dX[N] + gx[N])
         for k in range(N - 1, 0, -1):
-            lamn[k] = AB[k][0].T @ lamn[k + 1] - ((Hxx[k] + delta * np.eye(nx)) @ dX[k] + Hux[k].T @ dU[k] + gx[k])
+            lamn[k] = AB[k][0].T @ lamn[k + 1] - ((Hxx[k] + Dx) @ dX[k] + Hux[k].T @ dU[k] + gx[k])
         # slack / dual steps
         dSx, dZx, dSu, dZu = [], [], [], []
         for k in range(N + 1):
@@ -353,6 +357,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         # penalty parameter (Nocedal-Wright 18.36 style with rho = 0.1)
         if th0 > 0:
             nu_trial = dphi / ((1 - 0.1) * th0)
+            nu_pen = max(1.0, 0.5 * nu_pen)
             if nu_pen < nu_trial:
                 nu_pen = nu_trial + 1.0
         D = dphi - nu_pen * th0

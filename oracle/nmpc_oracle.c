@@ -20,7 +20,8 @@
  *           slack/barrier reformulation, monotone mu update (their eq. 7 with
  *           kappa_mu=0.2, theta_mu=1.5, kappa_eps=10), fraction-to-boundary (eq. 8, 15),
  *           dual safeguard (eq. 16), scaled optimality error (eq. 5-6, s_max=100),
- *           inertia correction schedule (alg. IC), bound_push=1e-2; the linear system
+ *           inertia correction schedule (alg. IC) with the shift delta applied to the control
+ *           diagonal only (every Quu_k > 0 is what the Riccati sweep needs), bound_push=1e-2; the linear system
  *           is solved by a Riccati sweep over the stages (block elimination of the same
  *           KKT matrix) and the line search is an l1-merit backtracking search instead
  *           of IPOPT's filter.  Parity is therefore at the KKT point, not on iterates.
@@ -440,7 +441,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         for (;;) {
             ok = 1;
             memcpy(P, w->Hxx + (size_t)N * nx * nx, sizeof(double) * nx * nx);
-            for (int c = 0; c < nx; c++) { P[c * nx + c] += delta; pv[c] = w->gx[(size_t)N * nx + c]; }
+            for (int c = 0; c < nx; c++) pv[c] = w->gx[(size_t)N * nx + c];   /* the inertia shift acts on the controls only */
             for (int k = N - 1; k >= 0; k--) {
                 const double *u = w->U + (size_t)k * nu, *Ck = w->C + (size_t)k * nx;
                 const int nz = nx + nu;
@@ -496,7 +497,6 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                             for (int t = 0; t < nu; t++) a -= Qux[t * nx + r] * Qux[t * nx + c];
                             P[r * nx + c] = a;
                         }
-                        P[r * nx + r] += delta;
                         double a = qx[r] + w->gx[(size_t)k * nx + r];
                         for (int t = 0; t < nu; t++) a -= Qux[t * nx + r] * qu[t];
                         pv[r] = a;
@@ -551,7 +551,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             const double *Hk = w->Hxx + (size_t)k * nx * nx, *dx = w->dX + (size_t)k * nx;
             double *l = w->lamn + (size_t)k * nx;
             for (int r = 0; r < nx; r++) {
-                double a = w->gx[(size_t)k * nx + r] + delta * dx[r];
+                double a = w->gx[(size_t)k * nx + r];
                 for (int c = 0; c < nx; c++) a += Hk[r * nx + c] * dx[c];
                 l[r] = -a;
             }
@@ -593,6 +593,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             /* Nocedal-Wright (18.36) with rho = 0.1.  In exact arithmetic dphi <= ||multipliers+||_inf * theta, so the
                quotient never exceeds mult_max / 0.9; the cap only filters the case theta ~ rounding noise. */
             double nut = fmin(dphi / ((1.0 - 0.1) * th0), mult_max / (1.0 - 0.1));
+            nu_pen = fmax(1.0, 0.5 * nu_pen);      /* the penalty may relax again: one bad step must not cripple the rest of the solve */
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         double D = dphi - nu_pen * th0, alpha = a_p, ft = f;

@@ -33,9 +33,9 @@ t0.record(); r = s.solve_batch(P, W0); t1.record(); torch.cuda.synchronize()
 L.nmpc_debug_profile(s._h, out, 1)
 it = r["iters"].cpu().numpy()
 tot_it = it.sum()
-names = ["setup", "A kkt-error", "B0 stage packs", "B riccati", "C forward", "D frac-to-bnd", "E line search", "F multipliers", "G update"]
-cyc = np.array([out[i] for i in range(9)], dtype=np.float64)
+names = ["setup", "A kkt-error", "B0 stage packs", "B riccati: schur+gains+rest", "C forward", "D frac-to-bnd", "E line search", "F multipliers", "G update", "B riccati: pack+G pass", "B riccati: assembly", "B riccati: elimination"]
+cyc = np.array([out[i] for i in range(12)], dtype=np.float64)
 print(f"batch {B} ({name}): kernel {t0.elapsed_time(t1):.2f} ms, mean iters {it.mean():.1f}, max {it.max()}")
 for n, c in zip(names, cyc):
-    print(f"  {n:16s} {c / tot_it:12.0f} clock64-ticks/iter  {100 * c / cyc.sum():5.1f} %")
+    print(f"  {n:30s} {c / tot_it:12.0f} clock64-ticks/iter  {100 * c / cyc.sum():5.1f} %")
 print(f"  total            {cyc.sum() / tot_it:12.0f} ticks/iter  (clock64 = 100 MHz realtime on gfx9: x10 ns)")
