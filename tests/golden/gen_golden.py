@@ -1,0 +1,62 @@
+"""Generates tests/golden/slsqp_*.npz: (p, w0, w*, f*) triples of the reference NLP solved by an INDEPENDENT solver.
+
+    python tests/golden/gen_golden.py
+
+"scipy-SLSQP oracle, not CasADi/IPOPT": the reference's own solver stack (casadi, IPOPT) is not
+installed and the reference holds no vectors, so the golden solutions come from
+scipy.optimize.minimize(method='SLSQP') applied to oracle/nlp_ref.py's restatement of the NLP
+(C6:273-339), started from the reference's cold start (C6:398-400).  The literal start/goal
+sets of the scripts are instance 0 where they exist.  Each triple also stores the SLSQP
+solution re-polished from itself (w_pol) as a convergence witness.
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.optimize import Bounds, minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import nlp_ref as R  # noqa: E402
+from tests import helpers as Hh  # noqa: E402
+
+
+def slsqp(cfg, p, w0):
+    lbx, ubx, lbg, ubg = R.bounds(cfg)
+    eq = np.where(lbg == ubg)[0]; iq = np.where(lbg != ubg)[0]
+    cons = [{"type": "eq", "fun": lambda w: R.constraints(cfg, w, p)[eq] - lbg[eq], "jac": lambda w: R.jacobian(cfg, w, p)[eq]}]
+    if iq.size:
+        cons.append({"type": "ineq", "fun": lambda w: R.constraints(cfg, w, p)[iq] - lbg[iq], "jac": lambda w: R.jacobian(cfg, w, p)[iq]})
+    r = minimize(lambda w: R.objective(cfg, w, p), w0, jac=lambda w: R.grad_objective(cfg, w, p), bounds=Bounds(lbx, ubx),
+                 constraints=cons, method="SLSQP", options={"ftol": 1e-14, "maxiter": 1000})
+    return r
+
+
+def make(name, cfg, P):
+    rows = []
+    for p in P:
+        w0 = R.cold_start(cfg, p[: cfg.nx])
+        r = slsqp(cfg, p, w0)
+        r2 = slsqp(cfg, p, r.x)
+        # status 8 ("positive directional derivative") is SLSQP's way of saying it cannot improve below ftol = 1e-14
+        assert r.status in (0, 8) and r2.status in (0, 8), (name, r.message, r2.message)
+        k = R.kkt_report(cfg, r2.x, p, tol_active=1e-6)
+        assert k["stat"] < 1e-4 and k["eq"] < 1e-9 and k["ineq"] < 1e-9 and k["bnd"] < 1e-12, (name, k)
+        rows.append((p, w0, r.x, r.fun, r2.x, r2.fun))
+        print(name, "f* = %.9f  (polish moved w by %.1e)" % (r.fun, np.max(np.abs(r.x - r2.x))))
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slsqp_%s.npz" % name)
+    np.savez_compressed(out, p=np.stack([r[0] for r in rows]), w0=np.stack([r[1] for r in rows]), w=np.stack([r[2] for r in rows]),
+                        f=np.array([r[3] for r in rows]), w_pol=np.stack([r[4] for r in rows]), f_pol=np.array([r[5] for r in rows]))
+
+
+if __name__ == "__main__":
+    rng = np.random.Generator(np.random.PCG64(Hh.SEED0))
+    c1 = R.cfg_one(20)
+    make("one", c1, [np.array([0.0, 0.0, 0.0, 1.5, 1.5, 0.0])] + [Hh.instance(rng, c1) for _ in range(5)])   # C1:177 first goal
+    c2 = R.cfg_two(20)
+    close = np.array([-0.2, 0.0, 0.0, 0.2, 0.02, np.pi, 0.6, 0.0, 0.0, -0.6, 0.0, np.pi])
+    make("two", c2, [np.concatenate([R.C2_START, R.C2_GOAL]), close] + [Hh.instance(rng, c2) for _ in range(4)])
+    co = R.cfg_obs3(20)
+    make("obs3", co, [np.array([0.0, 0.2 + 0.1 * t, 1.2, 0.2 * t, 2.6, 1.57]) for t in range(4)])
+    c3 = R.NLPConfig(m=3, N=10, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
+    make("three", c3, [Hh.instance(rng, c3) for _ in range(3)])

@@ -1,0 +1,123 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nmpc.h declares (no compute calls without a GPU);
+the Python host mirrors the reference call surface; sharding helpers; gloo world_size-2 gather."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import nlp_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(built):
+    import nmpc_amd
+    hdr = open(os.path.join(ROOT, "include", "nmpc.h")).read()
+    names = set(re.findall(r"\b(nmpc_[a-z_0-9]+)\s*\(", hdr))
+    assert {"nmpc_create", "nmpc_destroy", "nmpc_solve_batch", "nmpc_eval_batch", "nmpc_shift_batch"} <= names
+    L = nmpc_amd._lib.load()
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(nmpc_amd._lib.EXPORTS) == names
+    assert b"gfx950" in L.nmpc_version()
+
+
+def test_sizes_defaults_and_config_mirror(built):
+    import nmpc_amd
+    L = nmpc_amd._lib.load()
+    for cfg, oc in ((nmpc_amd.centralized_one_robot(20), R.cfg_one(20)), (nmpc_amd.centralized_two_robots(20), R.cfg_two(20)),
+                    (nmpc_amd.centralized_six_robots(20), R.cfg_six(20)), (nmpc_amd.ten_robots_collision_avoidance(30), R.cfg_ten(30)),
+                    (nmpc_amd.third_scenario_obstacles(20), R.cfg_obs3(20))):
+        cc = cfg.to_c()
+        assert L.nmpc_n_var(C.byref(cc)) == oc.n_var == cfg.n_var
+        assert L.nmpc_n_g(C.byref(cc)) == oc.n_g == cfg.n_g
+        assert L.nmpc_n_p(C.byref(cc)) == 2 * oc.nx
+        for a, b in zip(cfg.bounds(), R.bounds(oc)):
+            np.testing.assert_array_equal(a, b)
+    # file-own horizons of the scripts
+    assert nmpc_amd.centralized_one_robot().N == 100 and nmpc_amd.centralized_two_robots().N == 70
+    assert nmpc_amd.centralized_six_robots().N == 35 and nmpc_amd.ten_robots_collision_avoidance().N == 20
+    d = nmpc_amd._lib.CConfig()
+    L.nmpc_config_default(C.byref(d), 6, 20)
+    assert (d.m, d.N, d.pad_rows, d.max_iter) == (6, 20, 1, 2000) and list(d.q) == [1.0, 5.0, 0.1] and list(d.r) == [0.5, 0.05]
+    assert d.tol == 1e-8 and d.xy_max == 10.0 and d.pad_value == 3.5 and np.isinf(d.th_max)
+
+
+def test_create_fails_loudly_without_gpu(built):
+    """no CPU fallback: on a box without a HIP device the handle cannot be created and the host class raises."""
+    import torch
+    import nmpc_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = nmpc_amd._lib.load()
+    cc = nmpc_amd.centralized_two_robots(20).to_c()
+    h = C.c_void_p()
+    assert L.nmpc_create(C.byref(cc), 4, C.byref(h)) == -3          # NMPC_E_HIP
+    bad = nmpc_amd.centralized_two_robots(20); bad.m = 7
+    assert L.nmpc_create(C.byref(bad.to_c()), 4, C.byref(h)) in (-2, -3)
+    with pytest.raises(RuntimeError):
+        nmpc_amd.nlpsol("solver", "ipopt", nmpc_amd.centralized_two_robots(20), {})
+    with pytest.raises(ValueError):
+        nmpc_amd.nlpsol("solver", "sqpmethod", nmpc_amd.centralized_two_robots(20), {})
+
+
+def test_product_never_imports_oracle():
+    """the oracle is the checker only: nothing in the package (host or native) references it."""
+    pkg = [d for d in os.listdir(ROOT) if d.endswith("_amd") and os.path.isdir(os.path.join(ROOT, d))][0]
+    banned = ("import oracle", "from oracle", "oracle_lib", "libnmpc_oracle", "nmpc_oracle_", "nlp_ref", "ipm_proto")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for b in banned:
+                    assert b not in txt, (f, b)
+    assert "oracle" not in open(os.path.join(ROOT, "nmpc_amd.py")).read()
+
+
+def test_host_shift_and_cold_start(built):
+    import nmpc_amd
+    t0, u0 = nmpc_amd.shift(0.05, 1.0, np.array([[1, 2], [3, 4], [5, 6]]))
+    assert t0 == 1.05 and u0.tolist() == [[3, 4], [5, 6], [5, 6]]
+    X = np.arange(12.0).reshape(4, 3)
+    np.testing.assert_array_equal(nmpc_amd.shift_states(X), np.vstack([X[1:], X[2:3]]))
+    cfg = nmpc_amd.centralized_two_robots(20)
+    np.testing.assert_array_equal(nmpc_amd.cold_start(cfg, R.C2_START), R.cold_start(R.cfg_two(20), R.C2_START))
+
+
+def test_shard_range_partitions_contiguously(built):
+    import nmpc_amd
+    for B in (1, 7, 4096, 8192, 513):
+        for world in (1, 2, 3, 8):
+            r = [nmpc_amd.shard_range(B, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_results_gloo_world2(tmp_path):
+    """the only collective of the multi-GPU path (result gather) rehearsed with gloo on CPU, world_size 2."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import nmpc_amd\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "B = 7\n"
+        "lo, hi = nmpc_amd.shard_range(B, r, w)\n"
+        "full = torch.arange(B * 3, dtype=torch.float64).reshape(B, 3)\n"
+        "out = nmpc_amd.gather_results(full[lo:hi].clone(), B)\n"
+        "st = nmpc_amd.gather_results(torch.arange(lo, hi, dtype=torch.int32), B)\n"
+        "assert torch.equal(out, full), out\n"
+        "assert st.tolist() == list(range(B))\n"
+        "dist.destroy_process_group()\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]

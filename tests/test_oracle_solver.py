@@ -1,0 +1,94 @@
+"""CPU: the C interior-point oracle pinned by independent evidence — scipy-SLSQP golden triples
+(tests/golden/, generator committed), the solver-independent KKT report and the numpy prototype."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nlp_ref as R, oracle_lib as O, ipm_proto as I
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {"one": R.cfg_one(20), "two": R.cfg_two(20), "obs3": R.cfg_obs3(20),
+         "three": R.NLPConfig(m=3, N=10, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_slsqp_golden(name):
+    """'scipy-SLSQP oracle, not CasADi/IPOPT'.  SLSQP's own accuracy is ~1e-5 in w (its polish run moves by up to
+    5e-5), the barrier offset of the interior point is ~ n_active * mu = 1e-7 in f."""
+    cfg = CASES[name]
+    z = np.load(os.path.join(GOLD, "slsqp_%s.npz" % name))
+    r = O.solve_batch(O.make_config(cfg, max_iter=500), z["p"], z["w0"])
+    assert (r["status"] == 0).all() and (r["kkt"] <= 1e-8).all()
+    df = np.abs(r["f"] - z["f_pol"]) / np.maximum(1.0, np.abs(z["f_pol"]))
+    dw = np.max(np.abs(r["x"] - z["w_pol"]), axis=1)
+    same = df < 1e-6
+    assert same.mean() >= 0.8, (df, dw)          # non-convex: a cold-start SLSQP may pick another basin
+    assert (dw[same] < 2e-4).all(), dw
+    # where the basin differs both must be KKT points, and ours is re-checked independently
+    for b in np.where(~same)[0]:
+        k = R.kkt_report(cfg, r["x"][b], z["p"][b], tol_active=1e-3)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-8 and k["ineq"] < 1e-8, k
+
+
+def test_oracle_solutions_are_kkt_points_six_robots():
+    from tests import helpers as Hh
+    cfg = R.cfg_six(20)
+    P, W0 = Hh.batch(cfg, 12, 2)
+    r = O.solve_batch(O.make_config(cfg, max_iter=500), P, W0)
+    assert (r["status"] == 0).all()
+    lbx, ubx, lbg, ubg = R.bounds(cfg)
+    for b in range(12):
+        k = R.kkt_report(cfg, r["x"][b], P[b], tol_active=1e-3)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-8 and k["ineq"] < 1e-8 and k["bnd"] == 0.0, (b, k)
+        assert r["f"][b] == pytest.approx(R.objective(cfg, r["x"][b], P[b]), rel=1e-12)
+        assert np.array_equal(r["x"][b][: cfg.nx], P[b][: cfg.nx])      # X_0 pinned to x0
+
+
+def test_literal_scenarios_converge():
+    """the scripts' own start/goal sets (C2:213-224, C6:364-388); the antipodal six-robot swap is the hard one."""
+    for cfg, s, g in ((R.cfg_two(20), R.C2_START, R.C2_GOAL), (R.cfg_six(20), R.C6_START, R.C6_GOAL)):
+        p = np.concatenate([s, g])[None]
+        r = O.solve_batch(O.make_config(cfg, max_iter=1000), p, R.cold_start(cfg, s)[None])
+        assert r["status"][0] == 0, (r["iters"], r["kkt"])
+        k = R.kkt_report(cfg, r["x"][0], p[0], tol_active=1e-3)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-8 and k["ineq"] < 1e-8
+
+
+def test_fixed_point_and_infeasible_start():
+    cfg = R.cfg_two(20)
+    p = np.concatenate([R.C2_GOAL, R.C2_GOAL])[None]
+    r = O.solve_batch(O.make_config(cfg), p, R.cold_start(cfg, R.C2_GOAL)[None])
+    assert r["status"][0] == 0 and abs(r["f"][0]) < 1e-7 and np.max(np.abs(r["x"][0][cfg.nx * 21:])) < 1e-5   # item 3: U = 0
+    # stage-0 pair row violated by the pinned x0 (the ten-robot literal x0 has coincident robots, C10:389)
+    bad = np.array([[0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 1.0, 1.0, 0.0, -1.0, -1.0, 0.0]])
+    w0 = R.cold_start(cfg, bad[0, :6])[None]
+    r = O.solve_batch(O.make_config(cfg), bad, w0)
+    assert r["status"][0] == 3 and r["iters"][0] == 0 and np.array_equal(r["x"][0], w0[0])
+
+
+def test_prototype_and_c_oracle_agree():
+    """two independent implementations (numpy dense blocks, C scalar loops) of the same algorithm."""
+    from tests import helpers as Hh
+    for cfg, idx in ((R.cfg_one(20), 0), (R.cfg_two(20), 1)):
+        P, W0 = Hh.batch(cfg, 4, idx)
+        r = O.solve_batch(O.make_config(cfg, max_iter=300), P, W0)
+        for b in range(4):
+            o = I.Opts(); o.max_iter = 300
+            rp = I.solve(cfg, P[b], W0[b], o)
+            assert rp["status"] == 0 and abs(rp["f"] - r["f"][b]) < 1e-6 * max(1, abs(rp["f"]))
+            assert np.max(np.abs(rp["x"] - r["x"][b])) < 1e-5
+
+
+def test_warm_start_closed_loop_runs():
+    """three closed-loop steps of AS/casadi_test.py:143-183 with the oracle: solve, plant step, shift."""
+    cfg = R.cfg_two(20)
+    oc = O.make_config(cfg, max_iter=500)
+    p = np.concatenate([R.C2_START, R.C2_GOAL])[None]; w = R.cold_start(cfg, R.C2_START)[None]
+    d0 = np.linalg.norm(p[0, :6] - p[0, 6:])
+    for _ in range(3):
+        r = O.solve_batch(oc, p, w)
+        assert r["status"][0] == 0
+        w, x0n = O.shift_batch(oc, p, r["x"])
+        p = p.copy(); p[:, :6] = x0n
+    assert np.linalg.norm(p[0, :6] - p[0, 6:]) < d0
