@@ -50,7 +50,7 @@ template <int M_, int THB> struct G2 {
     static constexpr int row_of(int e) { int a = 0; while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; } return a; }
     static constexpr int slice_lo(int t, int tpb) { return row_of(t * tpb); }
     static constexpr int slice_hi(int t, int tpb) { return row_of((t * tpb + tpb - 1 < NT) ? (t * tpb + tpb - 1) : (NT - 1)); }
-    static constexpr int KTS = ((NX + 1) * NU + 7) / 8 * 8;     // transposed gains per stage
+    static constexpr int KTS = (NU * LD + NU + 7) / 8 * 8;      // per stage: the NU pivot rows [Uuu | Uux | rhs] and the NU reciprocal pivots
 };
 
 // ---- single evaluation points.  Constraint values, slack steps and defects are recomputed at several places of an
@@ -80,6 +80,29 @@ template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&
         f(std::integral_constant<int, B>{});
         static_for<B + 1, E>(f);
     }
+}
+
+// LDS access through a per-thread byte offset fixed at kernel start plus a compile-time constant: lowers to
+// ds_read_b64 / ds_write_b64 with the constant in the instruction's offset field (no address arithmetic in the hot loops)
+__device__ __forceinline__ double lds_ld(const double *sm, int byteoff, int cbytes)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(sm) + byteoff + cbytes);
+}
+__device__ __forceinline__ void lds_st(double *sm, int byteoff, int cbytes, double v)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(sm) + byteoff + cbytes) = v;
+}
+
+// LDS-only synchronisation of the threads of one instance.  __syncthreads() also drains vmcnt, i.e. it waits for every
+// global load/store in flight — which would turn the stage-ahead prefetches of the sweeps into synchronous loads.  One
+// wave executes its LDS instructions in order, so a single-wave instance only needs the LDS counter and a compiler fence;
+// multi-wave instances add the hardware barrier.
+template <int TPB> __device__ __forceinline__ void lds_sync()
+{
+    // release/acquire fences restricted to the LDS address space ("local"): s_waitcnt lgkmcnt(0) only, vmcnt untouched
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if constexpr (TPB > 64) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // reciprocal: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, a third of the cost of an IEEE division chain)
@@ -175,12 +198,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *PV = Pf + NX * NX;            // [NX]      cost-to-go gradient p
     double *Gb = PV + NX;                 // [NX*LDG]  P [B A] and, in column NZ, p + P b
     double *UR = Gb + NX * G::LDG;        // [NU*LD]   published pivot rows
-    double *PK = UR + NU * LD;            // [PACK]    current stage pack
+    double *INV = UR + NU * LD;           // [NU]      reciprocal pivots (contiguous with UR: streamed out together)
+    double *PK = INV + NU;                // [PACK]    current stage pack
     double *PB = PK + G::PACK;            // [NX]
     double *D0 = PB + NX;                 // [NU]   pivots as assembled
     double *XS = D0 + NU;                 // [NX]
-    double *INV = XS + NX;                // [NU]   reciprocal pivots
-    double *RED = INV + NU;               // [8]
+    double *RED = XS + NX;                // [8]
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
@@ -205,7 +228,10 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         int s = a - NU, i = s / 3, d = s - 3 * i;
         return (d < 2) ? s : ((t == 0) ? s : (t == 1 ? 3 * i : 3 * i + 1));
     };
-    int ea[NTP], eac[NTP], ec[NTP], ga0[NTP], ga1[NTP], ga2[NTP], hoff[NTP], wa1[NTP], wa2[NTP];
+    // byte offsets into LDS (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries, the coefficient
+    // triple and the Hessian addition of the assembly; the two mirror positions of the Schur block in Pf / PV
+    const int oUR = (int)(UR - sm) * 8, oGb = (int)(Gb - sm) * 8, oPK = (int)(PK - sm) * 8, oPf = (int)(Pf - sm) * 8;
+    int ea[NTP], uoa[NTP], uoc[NTP], pg0[NTP], pg1[NTP], pg2[NTP], pca[NTP], pho[NTP], wa1[NTP], wa2[NTP];
     double dl[NTP];
 #pragma unroll
     for (int t = 0; t < NTP; t++) {
@@ -213,8 +239,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         if (e < NT) {
             while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
             const int c = a + e;          // e in [0, NZ-a]: columns a..NZ
-            ea[t] = a; eac[t] = a; ec[t] = c;
-            ga0[t] = term_ix(a, 0) * G::LDG + c; ga1[t] = term_ix(a, 1) * G::LDG + c; ga2[t] = term_ix(a, 2) * G::LDG + c;
+            ea[t] = a; uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
+            pg0[t] = oGb + 8 * (term_ix(a, 0) * G::LDG + c); pg1[t] = oGb + 8 * (term_ix(a, 1) * G::LDG + c); pg2[t] = oGb + 8 * (term_ix(a, 2) * G::LDG + c);
+            pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
             dl[t] = (c == a && a < NU) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
             int h = G::PK_ZERO;
             if (c == NZ) h = G::PK_G + a;
@@ -224,17 +251,26 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 int sa = a - NU, sc = c - NU, ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
                 if (da < 2 && dc < 2) h = (ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc);
             }
-            hoff[t] = h;
+            pho[t] = oPK + 8 * h;
             if (a >= NU) {
-                if (c == NZ) { wa1[t] = NX * NX + (a - NU); wa2[t] = wa1[t]; }                  // PV follows Pf
-                else { wa1[t] = (a - NU) * NX + (c - NU); wa2[t] = (c - NU) * NX + (a - NU); }
-            } else { wa1[t] = 0; wa2[t] = 0; }
-        } else { ea[t] = -1; eac[t] = 0; ec[t] = 0; ga0[t] = 0; ga1[t] = 0; ga2[t] = 0; hoff[t] = G::PK_ZERO; dl[t] = 0.0; wa1[t] = 0; wa2[t] = 0; }
+                if (c == NZ) { wa1[t] = oPf + 8 * (NX * NX + (a - NU)); wa2[t] = wa1[t]; }                  // PV follows Pf
+                else { wa1[t] = oPf + 8 * ((a - NU) * NX + (c - NU)); wa2[t] = oPf + 8 * ((c - NU) * NX + (a - NU)); }
+            } else { wa1[t] = oPf; wa2[t] = oPf; }
+        } else {
+            ea[t] = -1; uoa[t] = oUR; uoc[t] = oUR; pg0[t] = oGb; pg1[t] = oGb; pg2[t] = oGb; pca[t] = oPK + 8 * G::PK_CF; pho[t] = oPK + 8 * G::PK_ZERO;
+            dl[t] = 0.0; wa1[t] = oPf; wa2[t] = oPf;
+        }
     }
+    // the strictly lower part of the pivot-row buffer stays zero for the whole solve: the branch-free rank-1 update
+    // multiplies by UR[j][a], which must vanish for rows a < j that are already eliminated
+    for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
     // G pass: lane -> column gcol of [B A], rows grow0, grow0 + HG, ...
     const int gcol = tid % NZ, grow0 = tid / NZ;
     const bool gact = tid < HG * NZ;
     const int gx0 = term_ix(gcol, 0), gx1 = term_ix(gcol, 1), gx2 = term_ix(gcol, 2);
+    constexpr int GRPT = (NX + HG - 1) / HG;                                   // rows per thread in the G pass
+    const int gpb0 = oPf + 8 * (grow0 * NX + gx0), gpb1 = oPf + 8 * (grow0 * NX + gx1), gpb2 = oPf + 8 * (grow0 * NX + gx2);
+    const int gwb = oGb + 8 * (grow0 * G::LDG + gcol);
 
     // ---- load start, pin X_0, push into the interior of the simple bounds (IPOPT bound_push)
     const double bp = 1e-2;
@@ -617,7 +653,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double pkr[PKR];
 #pragma unroll
             for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
-            __syncthreads();
+            lds_sync<TPB>();
             for (int k = N - 1; k >= 0; k--) {
                 // ---- stage pack -> LDS; prefetch the next one
 #pragma unroll
@@ -626,29 +662,36 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 #pragma unroll
                     for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
                 }
-                __syncthreads();
-                // ---- G = P [B A] (<= 3 terms per column, lane = column) and its last column p + P b, b = -c_k
+                lds_sync<TPB>();
+                // ---- G = P [B A] (<= 3 terms per column, thread = column, rows strided) and its last column p + P b, b = -c_k
                 if (gact) {
                     const double c0 = PK[G::PK_CF + 3 * gcol], c1 = PK[G::PK_CF + 3 * gcol + 1], c2 = PK[G::PK_CF + 3 * gcol + 2];
-#pragma unroll 4
-                    for (int r = grow0; r < NX; r += HG)
-                        Gb[r * G::LDG + gcol] = c0 * Pf[r * NX + gx0] + c1 * Pf[r * NX + gx1] + c2 * Pf[r * NX + gx2];
+                    static_for<0, GRPT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if ((NX % HG == 0) || grow0 + n * HG < NX)
+                            lds_st(sm, gwb, 8 * n * HG * G::LDG,
+                                   c0 * lds_ld(sm, gpb0, 8 * n * HG * NX) + c1 * lds_ld(sm, gpb1, 8 * n * HG * NX) + c2 * lds_ld(sm, gpb2, 8 * n * HG * NX));
+                    });
                 }
                 for (int r = tid; r < NX; r += TPB) {
-                    double a = PV[r];
-#pragma unroll 6
-                    for (int c = 0; c < NX; c++) a -= Pf[r * NX + c] * PK[G::PK_C + c];
-                    Gb[r * G::LDG + NZ] = a;
+                    double a0 = PV[r], a1 = 0.0, a2 = 0.0;
+                    const int pr = oPf + 8 * r * NX;
+#pragma unroll
+                    for (int c = 0; c + 2 < NX; c += 3) {
+                        a0 = fma(-lds_ld(sm, pr, 8 * c), PK[G::PK_C + c], a0);
+                        a1 = fma(-lds_ld(sm, pr, 8 * (c + 1)), PK[G::PK_C + c + 1], a1);
+                        a2 = fma(-lds_ld(sm, pr, 8 * (c + 2)), PK[G::PK_C + c + 2], a2);
+                    }
+                    Gb[r * G::LDG + NZ] = a0 + (a1 + a2);
                 }
-                __syncthreads();
+                lds_sync<TPB>();
                 PROF_T(9);
                 // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
                 double mv[NTP];
 #pragma unroll
                 for (int t = 0; t < NTP; t++) {
-                    const int a = ea[t] < 0 ? 0 : ea[t];
-                    double v = PK[G::PK_CF + 3 * a] * Gb[ga0[t]] + PK[G::PK_CF + 3 * a + 1] * Gb[ga1[t]] + PK[G::PK_CF + 3 * a + 2] * Gb[ga2[t]];
-                    v += PK[hoff[t]] + dl[t] * delta;
+                    double v = lds_ld(sm, pca[t], 0) * lds_ld(sm, pg0[t], 0) + lds_ld(sm, pca[t], 8) * lds_ld(sm, pg1[t], 0) + lds_ld(sm, pca[t], 16) * lds_ld(sm, pg2[t], 0);
+                    v += lds_ld(sm, pho[t], 0) + dl[t] * delta;
                     mv[t] = v;
                     if (dl[t] != 0.0) D0[ea[t]] = v;
                 }
@@ -660,21 +703,20 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         // publish pivot row j: only the (at most two) slices that hold it
                         static_for<0, NTP>([&](auto tc) {
                             constexpr int t = decltype(tc)::value;
-                            if constexpr (G::slice_lo(t, TPB) <= j && j <= G::slice_hi(t, TPB)) { if (ea[t] == j) UR[j * LD + ec[t]] = mv[t]; }
+                            if constexpr (G::slice_lo(t, TPB) <= j && j <= G::slice_hi(t, TPB)) { if (ea[t] == j) lds_st(sm, uoc[t], 8 * j * LD, mv[t]); }
                         });
-                        __syncthreads();
+                        lds_sync<TPB>();
                         const double d = UR[j * LD + j];
                         if (!(d > 1e-9 * fabs(D0[j])) || !(d > 0.0)) ok = false;
                         else {
                             const double inv = rcp_nr(d);
                             if (tid == 0) INV[j] = inv;
-                            // rank-1 update of every live slice, branch-free (all LDS reads of the step issue back to back)
+                            // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
+                            // UR[j][a] is 0 (a < j) or annihilates the already published pivot row itself (a == j)
                             static_for<0, NTP>([&](auto tc) {
                                 constexpr int t = decltype(tc)::value;
-                                if constexpr (G::slice_hi(t, TPB) > j) {
-                                    const double upd = (UR[j * LD + eac[t]] * inv) * UR[j * LD + ec[t]];
-                                    mv[t] = (ea[t] > j) ? (mv[t] - upd) : mv[t];
-                                }
+                                if constexpr (G::slice_hi(t, TPB) > j)
+                                    mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
                             });
                         }
                     }
@@ -684,24 +726,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 // ---- what is left is [P_k | p_k]: back to LDS (both triangles)
                 if (k >= 1) {
 #pragma unroll
-                    for (int t = 0; t < NTP; t++) if (ea[t] >= NU) { Pf[wa1[t]] = mv[t]; Pf[wa2[t]] = mv[t]; }
+                    for (int t = 0; t < NTP; t++) if (ea[t] >= NU) { lds_st(sm, wa1[t], 0, mv[t]); lds_st(sm, wa2[t], 0, mv[t]); }
                 }
-                __syncthreads();
-                // ---- gains: one lane per column of [Qux | qu], back substitution in registers, stream out transposed
-                for (int col = tid; col <= NX; col += TPB) {
-                    double kc[NU];
-                    const int cc = (col < NX) ? NU + col : NZ;
-#pragma unroll
-                    for (int j = NU - 1; j >= 0; j--) {
-                        double acc = UR[j * LD + cc];
-#pragma unroll
-                        for (int c = j + 1; c < NU; c++) acc += UR[j * LD + c] * kc[c];
-                        kc[j] = -acc * INV[j];
-                    }
-                    double *kt = gkt + (size_t)k * G::KTS + col * NU;
-#pragma unroll
-                    for (int j = 0; j < NU; j++) kt[j] = kc[j];
-                }
+                lds_sync<TPB>();
+                // ---- stream the pivot rows and reciprocal pivots of this stage to HBM/L2 (coalesced).  No feedback gains are
+                //      formed: the forward sweep needs K dx + k for ONE dx only, i.e. one triangular solve per stage.
+                for (int e = tid; e < NU * LD + NU; e += TPB) gkt[(size_t)k * G::KTS + e] = UR[e];
             }
             if (ok) break;
             __syncthreads();
@@ -714,8 +744,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
         PROF_T(3);
 
-        // ============ C. forward sweep.  Gains stream back from HBM/L2 through a register ring filled PD stages ahead by
-        // all threads (coalesced), then through an LDS staging buffer (Gb is free here) from which the control lanes read.
+        // ============ C. forward sweep.  The stage factors stream back from HBM/L2 through a register ring filled PD stages
+        // ahead by all threads (coalesced), then through an LDS staging buffer (Gb is free here).  Per stage the control
+        // lanes form t = Uux dx + rhs and solve Uuu du = -t by back substitution with v_readlane broadcasts.
         {
             constexpr int KPT = (G::KTS + TPB - 1) / TPB, PD = 4;
             double kq[PD][KPT];
@@ -724,6 +755,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 #pragma unroll
                 for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; kq[d][t] = (d < N && e < G::KTS) ? gkt[(size_t)d * G::KTS + e] : 0.0; }
             for (int c = tid; c < NX; c += TPB) DX[c] = 0.0;
+            const int jrow = (tid < NU) ? tid : 0;
             for (int k0 = 0; k0 < N; k0 += PD) {
 #pragma unroll
                 for (int d = 0; d < PD; d++) {
@@ -735,14 +767,34 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 #pragma unroll
                             for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) kq[d][t] = gkt[(size_t)(k + PD) * G::KTS + e]; }
                         }
-                        __syncthreads();
-                        if (tid < NU) {
-                            double a = Gb[NX * NU + tid];
+                        lds_sync<TPB>();
+                        if (tid < 64) {      // the NU control lanes live in the first wave
+                            const double *row = Gb + jrow * LD;
+                            double t0 = row[NZ], t1 = 0.0, t2 = 0.0;
 #pragma unroll
-                            for (int c = 0; c < NX; c++) a += Gb[c * NU + tid] * DX[k * NX + c];
-                            DU[k * NU + tid] = a;
+                            for (int c = 0; c + 2 < NX; c += 3) {
+                                t0 = fma(row[NU + c], DX[k * NX + c], t0);
+                                t1 = fma(row[NU + c + 1], DX[k * NX + c + 1], t1);
+                                t2 = fma(row[NU + c + 2], DX[k * NX + c + 2], t2);
+                            }
+                            double tj = t0 + (t1 + t2);
+                            const double invj = Gb[NU * LD + jrow];
+                            double urow[NU];
+#pragma unroll
+                            for (int c = 0; c < NU; c++) urow[c] = row[c];
+                            double duj = 0.0;
+                            static_for<0, NU>([&](auto cc) {
+                                constexpr int c = NU - 1 - decltype(cc)::value;
+                                const double cand = -tj * invj;            // meaningful on lane c: all its later columns are in
+                                const long long bits = __double_as_longlong(cand);
+                                const int lo = __builtin_amdgcn_readlane((int)bits, c), hi = __builtin_amdgcn_readlane((int)(bits >> 32), c);
+                                const double duc = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                                if (tid == c) duj = duc;
+                                tj = fma(urow[c], duc, tj);                // rows j < c use it; rows j >= c are done (their tj is dead)
+                            });
+                            if (tid < NU) DU[k * NU + tid] = duj;
                         }
-                        __syncthreads();
+                        lds_sync<TPB>();
                         for (int i = tid; i < M_; i += TPB) {
                             const double *x = X + k * NX + 3 * i, *xn = x + NX, *u = U + k * NU + 2 * i, *dx = DX + k * NX + 3 * i, *du = DU + k * NU + 2 * i;
                             double s = SN[k * M_ + i], c = CS[k * M_ + i];
