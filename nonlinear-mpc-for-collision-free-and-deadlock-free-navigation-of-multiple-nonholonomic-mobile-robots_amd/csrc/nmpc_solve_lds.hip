@@ -666,11 +666,14 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 // ---- G = P [B A] (<= 3 terms per column, thread = column, rows strided) and its last column p + P b, b = -c_k
                 if (gact) {
                     const double c0 = PK[G::PK_CF + 3 * gcol], c1 = PK[G::PK_CF + 3 * gcol + 1], c2 = PK[G::PK_CF + 3 * gcol + 2];
+                    double p0[GRPT], p1[GRPT], p2[GRPT];          // all reads first (one LDS latency instead of GRPT)
                     static_for<0, GRPT>([&](auto nc) {
                         constexpr int n = decltype(nc)::value;
-                        if ((NX % HG == 0) || grow0 + n * HG < NX)
-                            lds_st(sm, gwb, 8 * n * HG * G::LDG,
-                                   c0 * lds_ld(sm, gpb0, 8 * n * HG * NX) + c1 * lds_ld(sm, gpb1, 8 * n * HG * NX) + c2 * lds_ld(sm, gpb2, 8 * n * HG * NX));
+                        p0[n] = lds_ld(sm, gpb0, 8 * n * HG * NX); p1[n] = lds_ld(sm, gpb1, 8 * n * HG * NX); p2[n] = lds_ld(sm, gpb2, 8 * n * HG * NX);
+                    });
+                    static_for<0, GRPT>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        if ((NX % HG == 0) || grow0 + n * HG < NX) lds_st(sm, gwb, 8 * n * HG * G::LDG, c0 * p0[n] + c1 * p1[n] + c2 * p2[n]);
                     });
                 }
                 for (int r = tid; r < NX; r += TPB) {
@@ -688,12 +691,21 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 PROF_T(9);
                 // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
                 double mv[NTP];
+                {
+                    double q0[NTP], q1[NTP], q2[NTP], r0[NTP], r1[NTP], r2[NTP], hh[NTP];     // all reads first
 #pragma unroll
-                for (int t = 0; t < NTP; t++) {
-                    double v = lds_ld(sm, pca[t], 0) * lds_ld(sm, pg0[t], 0) + lds_ld(sm, pca[t], 8) * lds_ld(sm, pg1[t], 0) + lds_ld(sm, pca[t], 16) * lds_ld(sm, pg2[t], 0);
-                    v += lds_ld(sm, pho[t], 0) + dl[t] * delta;
-                    mv[t] = v;
-                    if (dl[t] != 0.0) D0[ea[t]] = v;
+                    for (int t = 0; t < NTP; t++) {
+                        q0[t] = lds_ld(sm, pca[t], 0); q1[t] = lds_ld(sm, pca[t], 8); q2[t] = lds_ld(sm, pca[t], 16);
+                        r0[t] = lds_ld(sm, pg0[t], 0); r1[t] = lds_ld(sm, pg1[t], 0); r2[t] = lds_ld(sm, pg2[t], 0);
+                        hh[t] = lds_ld(sm, pho[t], 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTP; t++) {
+                        double v = q0[t] * r0[t] + q1[t] * r1[t] + q2[t] * r2[t];
+                        v += hh[t] + dl[t] * delta;
+                        mv[t] = v;
+                        if (dl[t] != 0.0) D0[ea[t]] = v;
+                    }
                 }
                 PROF_T(10);
                 // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
@@ -713,10 +725,14 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                             if (tid == 0) INV[j] = inv;
                             // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
                             // UR[j][a] is 0 (a < j) or annihilates the already published pivot row itself (a == j)
+                            double la[NTP], lc[NTP];
                             static_for<0, NTP>([&](auto tc) {
                                 constexpr int t = decltype(tc)::value;
-                                if constexpr (G::slice_hi(t, TPB) > j)
-                                    mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
+                                if constexpr (G::slice_hi(t, TPB) > j) { la[t] = lds_ld(sm, uoa[t], 8 * j * LD); lc[t] = lds_ld(sm, uoc[t], 8 * j * LD); }
+                            });
+                            static_for<0, NTP>([&](auto tc) {
+                                constexpr int t = decltype(tc)::value;
+                                if constexpr (G::slice_hi(t, TPB) > j) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
                             });
                         }
                     }
@@ -786,9 +802,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                             static_for<0, NU>([&](auto cc) {
                                 constexpr int c = NU - 1 - decltype(cc)::value;
                                 const double cand = -tj * invj;            // meaningful on lane c: all its later columns are in
-                                const long long bits = __double_as_longlong(cand);
-                                const int lo = __builtin_amdgcn_readlane((int)bits, c), hi = __builtin_amdgcn_readlane((int)(bits >> 32), c);
-                                const double duc = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+                                const double duc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), c),
+                                                                    __builtin_amdgcn_readlane(__double2loint(cand), c));
                                 if (tid == c) duj = duc;
                                 tj = fma(urow[c], duc, tj);                // rows j < c use it; rows j >= c are done (their tj is dead)
                             });
