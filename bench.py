@@ -144,7 +144,7 @@ def main():
                    (args.workload, ocfg.m, ocfg.N, ocfg.M, B), "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol},
         "solve_stats": {"mean_iters": sum_iters / (B * world), "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / (B * world), "max_kkt_converged": float(allst[:, 4].max())},
-        "roofline": {"bound": "mfma", "kernel": "solve_kernel<%d>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "kernel": "nmpc::solve_lds_kernel<%d,...>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                      "flops_per_launch": flops_launch, "kernel_ms": float(allst[0, 5]),
                      "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,

@@ -177,10 +177,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *X = sm;                       // [N1*NX]
     double *U = X + N1 * NX;              // [N*NU]
     double *LAM = U + N * NU;             // [N1*NX]   lam[k] pairs with defect c_{k-1}
-    double *DX = LAM + N1 * NX;           // [N1*NX]
-    double *DU = DX + N1 * NX;            // [N*NU]
-    double *RV = DU + N * NU;             // [N1*NX]   stage residuals of the adjoint recursion
-    double *SPp = RV + N1 * NX;           // [N1*NP]   pair slacks
+    double *SPp = LAM + N1 * NX;          // [N1*NP]   pair slacks
     double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
     double *SO = ZPp + N1 * NP;           // [N1*MK]   obstacle slacks
     double *ZO = SO + N1 * MK;            // [N1*MK]
@@ -190,9 +187,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *ZXU = ZXL + N1 * NXB;         // [N1*NXB]
     double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds: s = u - lb computed on the fly
     double *SUU = SUL + N * NU;           // [N*NU]    loses all relative accuracy once s ~ 1e-12 (active bound at mu = 1e-9)
-    double *SXL = SUU + N * NU;           // [N1*NXB]
-    double *SXU = SXL + N1 * NXB;         // [N1*NXB]
-    double *SN = SXU + N1 * NXB;          // [N*M]
+    double *SN = SUU + N * NU;            // [N*M]      (state-bound slacks are implicit: s = x + b, b - x; |x| <= 10 keeps them O(1) accurate)
     double *CS = SN + N * M_;             // [N*M]
     double *Pf = CS + N * M_;             // [NX*NX]   cost-to-go Hessian P (full symmetric storage)
     double *PV = Pf + NX * NX;            // [NX]      cost-to-go gradient p
@@ -200,10 +195,20 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *UR = Gb + NX * G::LDG;        // [NU*LD]   published pivot rows
     double *INV = UR + NU * LD;           // [NU]      reciprocal pivots (contiguous with UR: streamed out together)
     double *PK = INV + NU;                // [PACK]    current stage pack
-    double *PB = PK + G::PACK;            // [NX]
-    double *D0 = PB + NX;                 // [NU]   pivots as assembled
+    double *D0 = PK + G::PACK;            // [NU]      pivots as assembled
     double *XS = D0 + NU;                 // [NX]
     double *RED = XS + NX;                // [8]
+    // Overlays.  W1 = [Pf | PV | Gb] and W2 = [UR | INV | PK] are only live during the Riccati sweep; the step (DX, DU) is
+    // produced after it and consumed before the next one, so it lives in W1 when it fits; the stage residuals RV of the
+    // adjoint recursion and the forward-sweep staging of the factors live in W2.
+    constexpr int W1S = NX * NX + NX + NX * G::LDG, W2S = NU * LD + NU + G::PACK;
+    double *extra = RED + 8;
+    const bool ovA = N1 * NX + N * NU <= W1S, ovB = N1 * NX <= W2S;
+    double *DX = ovA ? Pf : extra;        // [N1*NX]
+    double *DU = DX + N1 * NX;            // [N*NU]
+    if (!ovA) extra += N1 * NX + N * NU;
+    double *RV = ovB ? UR : extra;        // [N1*NX]   stage residuals / QP multipliers of the adjoint recursion
+    double *FS = UR;                      // forward-sweep staging of one stage factor ([UR rows | INV], KTS doubles <= W2S)
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
@@ -362,10 +367,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             brow(SUL[ou], U[ou] + P.vmax, DU[ou], u0 + P.vmax); brow(SUU[ou], P.vmax - U[ou], -DU[ou], P.vmax - u0);
             brow(SUL[ou + 1], U[ou + 1] + P.wmax, DU[ou + 1], u1 + P.wmax); brow(SUU[ou + 1], P.wmax - U[ou + 1], -DU[ou + 1], P.wmax - u1);
             // state bounds of stage k+1
-            const int sb = (k + 1) * NXB + (2 + THB) * i;
-            brow(SXL[sb], X[ox + NX] + P.xymax, DX[ox + NX], n0 + P.xymax); brow(SXU[sb], P.xymax - X[ox + NX], -DX[ox + NX], P.xymax - n0);
-            brow(SXL[sb + 1], X[ox + NX + 1] + P.xymax, DX[ox + NX + 1], n1 + P.xymax); brow(SXU[sb + 1], P.xymax - X[ox + NX + 1], -DX[ox + NX + 1], P.xymax - n1);
-            if (THB) { brow(SXL[sb + 2], X[ox + NX + 2] + P.thmax, DX[ox + NX + 2], n2 + P.thmax); brow(SXU[sb + 2], P.thmax - X[ox + NX + 2], -DX[ox + NX + 2], P.thmax - n2); }
+            l += log(n0 + P.xymax) + log(P.xymax - n0) + log(n1 + P.xymax) + log(P.xymax - n1);
+            if (THB) l += log(n2 + P.thmax) + log(P.thmax - n2);
         }
         for (int it = tid; it < (N - 1) * NP; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         int k = e / NXB, s = e - k * NXB;
         if (k >= 1) {
             double v = X[k * NX + bst(s)], b = bvl(s), sl = fmax(v + b, bp), su = fmax(b - v, bp);
-            SXL[e] = sl; SXU[e] = su; ZXL[e] = mu / sl; ZXU[e] = mu / su;
-        } else { SXL[e] = 1.0; SXU[e] = 1.0; ZXL[e] = 0.0; ZXU[e] = 0.0; }
+            ZXL[e] = mu / sl; ZXU[e] = mu / su;
+        } else { ZXL[e] = 0.0; ZXU[e] = 0.0; }
     }
     __syncthreads();
     double f, lgs, th0, e_c, e_h;
@@ -471,12 +474,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 double zl0 = ZXL[sb], zu0 = ZXU[sb], zl1 = ZXL[sb + 1], zu1 = ZXU[sb + 1];
                 j0 = zl0 - zu0; j1 = zl1 - zu1;
                 zsum += zl0 + zu0 + zl1 + zu1;
-                double p0 = SXL[sb] * zl0, p1 = SXU[sb] * zu0, p2 = SXL[sb + 1] * zl1, p3 = SXU[sb + 1] * zu1;
+                double p0 = (x[3 * i] + P.xymax) * zl0, p1 = (P.xymax - x[3 * i]) * zu0, p2 = (x[3 * i + 1] + P.xymax) * zl1, p3 = (P.xymax - x[3 * i + 1]) * zu1;
                 szmax = fmax(szmax, fmax(fmax(p0, p1), fmax(p2, p3))); szmin = fmin(szmin, fmin(fmin(p0, p1), fmin(p2, p3)));
                 if (THB) {
                     double zl2 = ZXL[sb + 2], zu2 = ZXU[sb + 2];
                     j2 = zl2 - zu2; zsum += zl2 + zu2;
-                    double p4 = SXL[sb + 2] * zl2, p5 = SXU[sb + 2] * zu2;
+                    double p4 = (x[3 * i + 2] + P.thmax) * zl2, p5 = (P.thmax - x[3 * i + 2]) * zu2;
                     szmax = fmax(szmax, fmax(p4, p5)); szmin = fmin(szmin, fmin(p4, p5));
                 }
             }
@@ -562,9 +565,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 const int sb = k * NXB + (2 + THB) * i;
                 {   // bounds: v = mu/s - sigma (h - s), sigma = z/s, lower row gradient +1, upper row -1
                     auto bv = [&](double sv, double zv, double hv, double &hd) { double sg = zv / sv; hd += sg; return mu / sv - sg * (hv - sv); };
-                    g0 -= bv(SXL[sb], ZXL[sb], x[3 * i] + P.xymax, h0) - bv(SXU[sb], ZXU[sb], P.xymax - x[3 * i], h0);
-                    g1 -= bv(SXL[sb + 1], ZXL[sb + 1], x[3 * i + 1] + P.xymax, h1) - bv(SXU[sb + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], h1);
-                    if (THB) g2 -= bv(SXL[sb + 2], ZXL[sb + 2], x[3 * i + 2] + P.thmax, h2) - bv(SXU[sb + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], h2);
+                    g0 -= bv(x[3 * i] + P.xymax, ZXL[sb], x[3 * i] + P.xymax, h0) - bv(P.xymax - x[3 * i], ZXU[sb], P.xymax - x[3 * i], h0);
+                    g1 -= bv(x[3 * i + 1] + P.xymax, ZXL[sb + 1], x[3 * i + 1] + P.xymax, h1) - bv(P.xymax - x[3 * i + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], h1);
+                    if (THB) g2 -= bv(x[3 * i + 2] + P.thmax, ZXL[sb + 2], x[3 * i + 2] + P.thmax, h2) - bv(P.thmax - x[3 * i + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], h2);
                 }
                 if (k <= N - 1) {
                     const double xi = x[3 * i], yi = x[3 * i + 1];
@@ -648,6 +651,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 }
                 for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
             }
+            // the pivot-row area doubles as staging / residual storage between sweeps: restore the zero lower part the
+            // select-free rank-1 update relies on
+            for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
             // prefetch pack N-1 into registers
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
             double pkr[PKR];
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         PROF_T(3);
 
         // ============ C. forward sweep.  The stage factors stream back from HBM/L2 through a register ring filled PD stages
-        // ahead by all threads (coalesced), then through an LDS staging buffer (Gb is free here).  Per stage the control
+        // ahead by all threads (coalesced), then through an LDS staging buffer (the pivot-row area, free here).  Per stage the control
         // lanes form t = Uux dx + rhs and solve Uuu du = -t by back substitution with v_readlane broadcasts.
         {
             constexpr int KPT = (G::KTS + TPB - 1) / TPB, PD = 4;
@@ -778,14 +784,14 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     const int k = k0 + d;
                     if (k < N) {
 #pragma unroll
-                        for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) Gb[e] = kq[d][t]; }
+                        for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) FS[e] = kq[d][t]; }
                         if (k + PD < N) {
 #pragma unroll
                             for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) kq[d][t] = gkt[(size_t)(k + PD) * G::KTS + e]; }
                         }
                         lds_sync<TPB>();
                         if (tid < 64) {      // the NU control lanes live in the first wave
-                            const double *row = Gb + jrow * LD;
+                            const double *row = FS + jrow * LD;
                             double t0 = row[NZ], t1 = 0.0, t2 = 0.0;
 #pragma unroll
                             for (int c = 0; c + 2 < NX; c += 3) {
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                                 t2 = fma(row[NU + c + 2], DX[k * NX + c + 2], t2);
                             }
                             double tj = t0 + (t1 + t2);
-                            const double invj = Gb[NU * LD + jrow];
+                            const double invj = FS[NU * LD + jrow];
                             double urow[NU];
 #pragma unroll
                             for (int c = 0; c < NU; c++) urow[c] = row[c];
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         }
         for (int e = tid; e < N * NXB; e += TPB) {
             int k = 1 + e / NXB, s = e - (k - 1) * NXB;
-            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = SXL[k * NXB + s], su = SXU[k * NXB + s];
+            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = v + b, su = b - v;
             fb(sl, ZXL[k * NXB + s], dv + ((v + b) - sl)); fb(su, ZXU[k * NXB + s], -dv + ((b - v) - su));
         }
         for (int it = tid; it < (N - 1) * NP; it += TPB) {
@@ -870,9 +876,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             {   // bounds: z + dz, dz = (mu - s z - z ds)/s, ds = +-dx + (h - s)
                 const int sb = k * NXB + (2 + THB) * i;
                 auto zn = [&](double sv, double zv, double hv, double jd) { double ds = jd + (hv - sv); return zv + dz_of(mu, sv, zv, ds); };
-                l0 = zn(SXL[sb], ZXL[sb], x[3 * i] + P.xymax, dx[3 * i]) - zn(SXU[sb], ZXU[sb], P.xymax - x[3 * i], -dx[3 * i]);
-                l1 = zn(SXL[sb + 1], ZXL[sb + 1], x[3 * i + 1] + P.xymax, dx[3 * i + 1]) - zn(SXU[sb + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], -dx[3 * i + 1]);
-                if (THB) l2 = zn(SXL[sb + 2], ZXL[sb + 2], x[3 * i + 2] + P.thmax, dx[3 * i + 2]) - zn(SXU[sb + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], -dx[3 * i + 2]);
+                l0 = zn(x[3 * i] + P.xymax, ZXL[sb], x[3 * i] + P.xymax, dx[3 * i]) - zn(P.xymax - x[3 * i], ZXU[sb], P.xymax - x[3 * i], -dx[3 * i]);
+                l1 = zn(x[3 * i + 1] + P.xymax, ZXL[sb + 1], x[3 * i + 1] + P.xymax, dx[3 * i + 1]) - zn(P.xymax - x[3 * i + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], -dx[3 * i + 1]);
+                if (THB) l2 = zn(x[3 * i + 2] + P.thmax, ZXL[sb + 2], x[3 * i + 2] + P.thmax, dx[3 * i + 2]) - zn(P.thmax - x[3 * i + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], -dx[3 * i + 2]);
             }
             if (k < N) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 #pragma unroll
                 for (int d = 0; d < 2 + THB; d++) {
                     const int sb = k * NXB + (2 + THB) * i + d;
-                    double v = X[k * NX + 3 * i + d], dv = DX[k * NX + 3 * i + d], b = (d == 2) ? P.thmax : P.xymax, sl = SXL[sb], su = SXU[sb];
+                    double v = X[k * NX + 3 * i + d], dv = DX[k * NX + 3 * i + d], b = (d == 2) ? P.thmax : P.xymax, sl = v + b, su = b - v;
                     dphi -= mu * ((dv + ((v + b) - sl)) / sl + (-dv + ((b - v) - su)) / su);
                 }
             }
@@ -991,17 +997,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double znl = zl + (mu - sl * zl - zl * dsl) / sl, znu = zu + (mu - su * zu - zu * dsu) / su;
             double lin = 2 * P.r[0] * (u0 + du0) - T * (CS[0] * RV[NX] + SN[0] * RV[NX + 1]) - (znl - znu);
             double *tr2 = reinterpret_cast<double *>(prof_out + 12 + 16 * 2048) + (size_t)iter * 8;
-            // Riccati-implied multiplier of stage 1, -(P_1 dx_1 + p_1), against the adjoint recursion (Pf/PV still hold P_1, p_1)
-            double dmax = 0.0, lr0 = 0.0;
-            for (int c = 0; c < NX; c++) {
-                double a = PV[c];
-                for (int j = 0; j < NX; j++) a += Pf[c * NX + j] * DX[NX + j];
-                double d = fabs(-a - RV[NX + c]);
-                if (d > dmax) dmax = d;
-                if (c == 0) lr0 = -a;
-            }
-            double lin2 = 2 * P.r[0] * (u0 + du0) - T * (CS[0] * lr0 + SN[0] * (-(PV[1] + [&]{ double a = 0; for (int j = 0; j < NX; j++) a += Pf[NX + j] * DX[NX + j]; return a; }()))) - (znl - znu);
-            tr2[5] = lin; tr2[6] = dmax; tr2[7] = lin2;
+            tr2[5] = lin; tr2[6] = du0; tr2[7] = dsu;
         }
         if (prof_out && tid == 0 && (int)inst == P.trace_inst && iter < 2040) {
             double *tr = reinterpret_cast<double *>(prof_out + 12) + (size_t)iter * 16;
@@ -1026,9 +1022,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         for (int e = tid; e < N * NXB; e += TPB) {
             int k = 1 + e / NXB, s = e - (k - 1) * NXB;
             const int es = k * NXB + s;
-            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = SXL[es], su = SXU[es], sn;
-            ZXL[es] = zup(sl, ZXL[es], dv + ((v + b) - sl), sn); SXL[es] = sn;
-            ZXU[es] = zup(su, ZXU[es], -dv + ((b - v) - su), sn); SXU[es] = sn;
+            double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = v + b, su = b - v, sn;
+            ZXL[es] = zup(sl, ZXL[es], dv + ((v + b) - sl), sn);
+            ZXU[es] = zup(su, ZXU[es], -dv + ((b - v) - su), sn);
         }
         for (int it = tid; it < (N - 1) * NP; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
@@ -1077,8 +1073,10 @@ template <int M_, int THB> static size_t lds_bytes(const KParams &P)
 {
     using G = G2<M_, THB>;
     const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
-    size_t d = N1 * G::NX * 4 + N * G::NU * 6 + N1 * G::NP * 2 + N1 * MK * 2 + N1 * G::NXB * 4 + N * M_ * 2 + (size_t)G::NX * G::NX + G::NX + (size_t)G::NX * G::LDG + (size_t)G::NU * G::LD +
-               G::PACK + G::NX * 2 + G::NU * 2 + 8;
+    const size_t W1S = (size_t)G::NX * G::NX + G::NX + (size_t)G::NX * G::LDG, W2S = (size_t)G::NU * G::LD + G::NU + G::PACK;
+    size_t d = N1 * G::NX * 2 + N * G::NU * 5 + N1 * G::NP * 2 + N1 * MK * 2 + N1 * G::NXB * 2 + N * M_ * 2 + W1S + W2S + G::NU + G::NX + 8;
+    if (N1 * G::NX + N * G::NU > W1S) d += N1 * G::NX + N * G::NU;      // step does not fit the Riccati working area
+    if (N1 * G::NX > W2S) d += N1 * G::NX;
     return d * sizeof(double);
 }
 
