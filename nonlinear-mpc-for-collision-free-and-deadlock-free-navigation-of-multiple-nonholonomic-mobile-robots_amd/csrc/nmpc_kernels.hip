@@ -315,6 +315,8 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     __syncthreads();
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;
+    int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
     const double n_ineq = (double)P.n_ineq;
 
@@ -729,10 +731,17 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         }
         const double D = dphi - nu_pen * th0;
         double alpha = a_p;
+        if (mh_mu != mu || mh_nu != nu_pen) { mcount = 0; mh_mu = mu; mh_nu = nu_pen; }
+        const double m0 = phi0 + nu_pen * th0;
+        double mref = m0;
+        if (mcount > 0) mref = fmax(mref, mh0);
+        if (mcount > 1) mref = fmax(mref, mh1);
+        if (mcount > 2) mref = fmax(mref, mh2);
+        mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
         for (int ls = 0; ls < 30; ls++) {
             double phit, tht;
             eval_trial(alpha, mu, phit, tht);
-            if (phit + nu_pen * tht <= phi0 + nu_pen * th0 + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
+            if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
         __syncthreads();

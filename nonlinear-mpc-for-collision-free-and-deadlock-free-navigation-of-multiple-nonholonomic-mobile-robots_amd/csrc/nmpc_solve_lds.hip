@@ -48,6 +48,7 @@ template <int M_, int THB> struct G2 {
     // element e of the row-major upper triangle (+ rhs column) lives in row row_of(e); thread tid owns e = tid + t*TPB, so
     // "slice" t holds rows slice_lo(t)..slice_hi(t): compile-time knowledge of which slices a pivot step touches
     static constexpr int row_of(int e) { int a = 0; while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; } return a; }
+    static constexpr int diag_e(int j) { int e = 0; for (int a = 0; a < j; a++) e += NZ - a + 1; return e; }   // flat index of element (j,j)
     static constexpr int slice_lo(int t, int tpb) { return row_of(t * tpb); }
     static constexpr int slice_hi(int t, int tpb) { return row_of((t * tpb + tpb - 1 < NT) ? (t * tpb + tpb - 1) : (NT - 1)); }
     static constexpr int KTS = (NU * LD + NU + 7) / 8 * 8;      // per stage: the NU pivot rows [Uuu | Uux | rhs] and the NU reciprocal pivots
@@ -444,6 +445,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     merit(0.0, f, lgs, th0, e_c, e_h);
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
+    int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
     const double n_ineq = (double)P.n_ineq;
     PROF_T(0);
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 lds_sync<TPB>();
                 PROF_T(9);
                 // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
-                double mv[NTP];
+                double mv[NTP], d0r[NTP];      // d0r: values as assembled (the owners of the control diagonals test their pivot against it)
                 {
                     double q0[NTP], q1[NTP], q2[NTP], r0[NTP], r1[NTP], r2[NTP], hh[NTP];     // all reads first
 #pragma unroll
@@ -710,25 +713,30 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         double v = q0[t] * r0[t] + q1[t] * r1[t] + q2[t] * r2[t];
                         v += hh[t] + dl[t] * delta;
                         mv[t] = v;
-                        if (dl[t] != 0.0) D0[ea[t]] = v;
+                        d0r[t] = v;
                     }
                 }
                 PROF_T(10);
                 // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
+                // pivot test + reciprocal of pivot j: evaluated by every thread on its own slice element, meaningful on the owner
+                // of (j,j); < 0 flags a non-positive pivot.  It is computed right after the slice holding (j,j) got its last
+                // update, so its latency hides under the rank-1 updates of the other slices.
+                auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0) && d > 0.0) ? rcp_nr(d) : -1.0; };
+                double inv_own = pivot_inv(mv[G::diag_e(0) / TPB], d0r[G::diag_e(0) / TPB]);
                 static_for<0, NU>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
+                    constexpr int td = G::diag_e(j) / TPB;
                     if (ok) {
-                        // publish pivot row j: only the (at most two) slices that hold it
+                        // publish pivot row j (only the at most two slices that hold it) and its reciprocal pivot
                         static_for<0, NTP>([&](auto tc) {
                             constexpr int t = decltype(tc)::value;
                             if constexpr (G::slice_lo(t, TPB) <= j && j <= G::slice_hi(t, TPB)) { if (ea[t] == j) lds_st(sm, uoc[t], 8 * j * LD, mv[t]); }
                         });
+                        if (ea[td] == j && dl[td] != 0.0) INV[j] = inv_own;
                         lds_sync<TPB>();
-                        const double d = UR[j * LD + j];
-                        if (!(d > 1e-9 * fabs(D0[j])) || !(d > 0.0)) ok = false;
+                        const double inv = INV[j];
+                        if (!(inv > 0.0)) ok = false;
                         else {
-                            const double inv = rcp_nr(d);
-                            if (tid == 0) INV[j] = inv;
                             // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
                             // UR[j][a] is 0 (a < j) or annihilates the already published pivot row itself (a == j)
                             double la[NTP], lc[NTP];
@@ -736,10 +744,20 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                                 constexpr int t = decltype(tc)::value;
                                 if constexpr (G::slice_hi(t, TPB) > j) { la[t] = lds_ld(sm, uoa[t], 8 * j * LD); lc[t] = lds_ld(sm, uoc[t], 8 * j * LD); }
                             });
-                            static_for<0, NTP>([&](auto tc) {
-                                constexpr int t = decltype(tc)::value;
-                                if constexpr (G::slice_hi(t, TPB) > j) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
-                            });
+                            if constexpr (j + 1 < NU) {
+                                constexpr int tn = G::diag_e(j + 1) / TPB;       // slice of the next pivot: update it first
+                                mv[tn] = fma(-(la[tn] * inv), lc[tn], mv[tn]);
+                                inv_own = pivot_inv(mv[tn], d0r[tn]);
+                                static_for<0, NTP>([&](auto tc) {
+                                    constexpr int t = decltype(tc)::value;
+                                    if constexpr (G::slice_hi(t, TPB) > j && t != tn) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
+                                });
+                            } else {
+                                static_for<0, NTP>([&](auto tc) {
+                                    constexpr int t = decltype(tc)::value;
+                                    if constexpr (G::slice_hi(t, TPB) > j) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
+                                });
+                            }
                         }
                     }
                 });
@@ -983,9 +1001,17 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         }
         const double Dm = dphi - nu_pen * th0;
         double alpha = a_p, ft, lgt, tht, ect, eht;
+        // non-monotone (Grippo-type) reference value: max of the current and the last three merit values of this barrier problem
+        if (mh_mu != mu || mh_nu != nu_pen) { mcount = 0; mh_mu = mu; mh_nu = nu_pen; }
+        const double m0 = phi0 + nu_pen * th0;
+        double mref = m0;
+        if (mcount > 0) mref = fmax(mref, mh0);
+        if (mcount > 1) mref = fmax(mref, mh1);
+        if (mcount > 2) mref = fmax(mref, mh2);
+        mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
         for (int ls = 0; ls < 30; ls++) {
             merit(alpha, ft, lgt, tht, ect, eht);
-            if ((ft - mu * lgt) + nu_pen * tht <= phi0 + nu_pen * th0 + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
+            if ((ft - mu * lgt) + nu_pen * tht <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
         PROF_T(6);

@@ -150,6 +150,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
     lam = np.zeros((N + 1, nx))     # lam[k+1] pairs with defect c_k
     delta_last = 0.0
     nu_pen = 1.0
+    mhist = []; mh_key = None
     hist = []
     sweeps_total = [0]
 
@@ -361,6 +362,11 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             if nu_pen < nu_trial:
                 nu_pen = nu_trial + 1.0
         D = dphi - nu_pen * th0
+        if mh_key != (mu, nu_pen):
+            mhist = []; mh_key = (mu, nu_pen)
+        m0 = phi0 + nu_pen * th0
+        mref = max([m0] + mhist[:3])
+        mhist = [m0] + mhist[:2]
         alpha = a_p
         accepted = False
         for ls in range(o.ls_max):
@@ -369,7 +375,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             fn, Cn, Hxn, Hun = eval_all(Xn, Un)
             thn = infeas(Cn, Hxn, Hun, Sxn, Sun)
             phin = barrier_phi(fn, Sxn, Sun, mu)
-            if (phin + nu_pen * thn) <= (phi0 + nu_pen * th0) + o.eta * alpha * D + 1e-13 * abs(phi0):
+            if (phin + nu_pen * thn) <= mref + o.eta * alpha * D + 1e-13 * abs(phi0):
                 accepted = True; break
             alpha *= 0.5
         if not accepted:

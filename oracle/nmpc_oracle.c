@@ -23,8 +23,8 @@
  *           inertia correction schedule (alg. IC) with the shift delta applied to the control
  *           diagonal only (every Quu_k > 0 is what the Riccati sweep needs), bound_push=1e-2; the linear system
  *           is solved by a Riccati sweep over the stages (block elimination of the same
- *           KKT matrix) and the line search is an l1-merit backtracking search instead
- *           of IPOPT's filter.  Parity is therefore at the KKT point, not on iterates.
+ *           KKT matrix) and the line search is a non-monotone l1-merit backtracking search
+ *           (reference = max of the last four merit values) instead of IPOPT's filter.  Parity is therefore at the KKT point, not on iterates.
  *   shift:  C6:160-169,460-465; plant step AllScripts/casadi_test.py:17-26.
  *
  * Plain scalar C99, one instance at a time; the batch driver runs instances in
@@ -307,6 +307,8 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         }
     memset(w->lam, 0, sizeof(double) * (size_t)(N + 1) * nx);
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   /* merit values of the last three iterates (same mu, nu) */
+    int mcount = 0;
     int it = 0;
     int n_ineq = 0;
     for (int k = 0; k <= N; k++) for (int s = 0; s < nh; s++) n_ineq += slot_active(w, k, s);
@@ -597,13 +599,22 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             if (nu_pen < nut) nu_pen = nut + 1.0;
         }
         double D = dphi - nu_pen * th0, alpha = a_p, ft = f;
+        /* non-monotone (Grippo-type) reference: the trial merit is compared with the largest of the current and the last
+           three merit values of this barrier problem; cures the Maratos-type rejections of full steps near the solution */
+        if (mh_mu != mu || mh_nu != nu_pen) { mcount = 0; mh_mu = mu; mh_nu = nu_pen; }
+        const double m0 = phi0 + nu_pen * th0;
+        double mref = m0;
+        if (mcount > 0) mref = fmax(mref, mh0);
+        if (mcount > 1) mref = fmax(mref, mh1);
+        if (mcount > 2) mref = fmax(mref, mh2);
+        mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
         for (int ls = 0; ls < 30; ls++) {
             for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
             for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
             for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + alpha * w->dS[i];
             ft = eval_point(w, xs, w->Xt, w->Ut, w->snt, w->cst, w->Ct, w->Ht);
             double tht, phit = barrier_and_infeas(w, ft, w->Ct, w->Ht, w->St, mu, &tht);
-            if (phit + nu_pen * tht <= phi0 + nu_pen * th0 + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
+            if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
         /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
