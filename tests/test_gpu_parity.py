@@ -80,6 +80,37 @@ def test_warm_start_matches_oracle(built):
     assert (dw <= W_TOL).mean() >= 0.85, dw
 
 
+def _composite_cfg(N=25, seed=7):
+    """BASELINE.json config 5 (synthetic composite, no reference script): six-robot pair rows + 8 circular obstacles."""
+    rng = np.random.default_rng(seed)
+    obs = [(float(x), float(y), float(r)) for x, y, r in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
+    c = R.cfg_six(N); c.obstacles = obs; c.rob_dim = 0.2; c.margin = 0.1
+    return c
+
+
+@pytest.mark.parametrize("name,ocfg,B,idx", [
+    ("one_N100", R.cfg_one(100), 8, 0), ("two_N70", R.cfg_two(70), 8, 1), ("six_N35", R.cfg_six(35), 8, 2),
+    ("ten_N30", R.cfg_ten(30), 8, 3), ("composite_N25", _composite_cfg(25), 24, 4),
+    ("three", R.NLPConfig(m=3, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5), 32, 5),
+    ("five", R.NLPConfig(m=5, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5), 32, 5),
+    ("eight", R.NLPConfig(m=8, N=20, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84), 16, 5),
+])
+def test_file_horizons_other_team_sizes_and_composite(built, name, ocfg, B, idx):
+    """the scripts' own horizons, the other team sizes of the reference (3, 5, 8 robots) and the
+    synthetic composite of BASELINE.json config 5, each against the oracle."""
+    import torch
+    P, W0 = Hh.batch(ocfg, B, idx)
+    s = _solver(ocfg, B, max_iter=600)
+    r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=600), P, W0)
+    assert (r["status"] == ref["status"]).all(), (r["status"], ref["status"])
+    conv = r["status"] == 0
+    assert conv.mean() >= 0.9
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    print(f"{name}: same-basin {(dw[conv] <= W_TOL).mean():.3f}, iters hip mean {r['iters'].mean():.1f} oracle {ref['iters'].mean():.1f}")
+    assert (dw[conv] <= W_TOL).mean() >= 0.85, dw
+
+
 def test_literal_scenarios(built):
     """the reference's own start/goal sets (C2:213-224, C6:364-388) as instance 0."""
     import torch
