@@ -32,6 +32,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + SOURCES
     if os.environ.get("NMPC_PROFILE"):
         cmd.insert(1, "-DNMPC_PROFILE")
+    if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30
+        cmd.insert(1, "-DNMPC_POISON=" + os.environ["NMPC_POISON"])
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

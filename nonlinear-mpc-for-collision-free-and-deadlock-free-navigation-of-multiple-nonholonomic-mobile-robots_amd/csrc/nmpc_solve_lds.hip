@@ -208,7 +208,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *DX = ovA ? Pf : extra;        // [N1*NX]
     double *DU = DX + N1 * NX;            // [N*NU]
     if (!ovA) extra += N1 * NX + N * NU;
-    double *RV = ovB ? UR : extra;        // [N1*NX]   stage residuals / QP multipliers of the adjoint recursion
+    double *RV = ovB ? UR : extra;        // [N1*NX]   stage residuals / QP multipliers of the adjoint recursion (ACT follows, see below)
     double *FS = UR;                      // forward-sweep staging of one stage factor ([UR rows | INV], KTS doubles <= W2S)
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
@@ -234,17 +234,40 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         int s = a - NU, i = s / 3, d = s - 3 * i;
         return (d < 2) ? s : ((t == 0) ? s : (t == 1 ? 3 * i : 3 * i + 1));
     };
-    // byte offsets into LDS (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries, the coefficient
-    // triple and the Hessian addition of the assembly; the two mirror positions of the Schur block in Pf / PV
+    // Static element ownership e -> (row a, col c) is decoded once and parked in LDS as 16-bit (a | c << 8) words; the
+    // per-element offset tables are rebuilt from it at the start of every sweep, so they only occupy registers while
+    // a sweep runs (kept for the whole kernel they cost ~100 VGPRs in every other phase and pushed the kernel into scratch).
     const int oUR = (int)(UR - sm) * 8, oGb = (int)(Gb - sm) * 8, oPK = (int)(PK - sm) * 8, oPf = (int)(Pf - sm) * 8;
+    unsigned short *ACT = reinterpret_cast<unsigned short *>(extra + ((ovB ? 0 : N1 * NX)));    // [NTP*TPB]
+#ifdef NMPC_POISON
+    {   // debug build: every LDS word and the instance's HBM workspace start as NMPC_POISON, so that a read of anything this
+        // solve did not write shows up as a parity failure instead of depending on what ran on the CU before
+        const int nl = (int)(reinterpret_cast<double *>(ACT) - sm) + (NTP * TPB * 2 + 7) / 8;
+        for (int e = tid; e < nl; e += TPB) sm[e] = NMPC_POISON;
+        for (int e = tid; e < P.stride2; e += TPB) ws[inst * P.stride2 + e] = NMPC_POISON;
+        __syncthreads();
+    }
+#endif
+#pragma unroll
+    for (int t = 0; t < NTP; t++) {
+        int e = tid + t * TPB, a = 0;
+        unsigned short w = 0xFFFF;
+        if (e < NT) {
+            while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
+            w = (unsigned short)(a | ((a + e) << 8));          // e in [0, NZ-a]: columns a..NZ
+        }
+        ACT[t * TPB + tid] = w;
+    }
+    __syncthreads();
+    // ---- per-element LDS byte offsets (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries,
+    //      the coefficient triple and the Hessian addition of the assembly; the mirror positions of the Schur block
     int ea[NTP], uoa[NTP], uoc[NTP], pg0[NTP], pg1[NTP], pg2[NTP], pca[NTP], pho[NTP], wa1[NTP], wa2[NTP];
     double dl[NTP];
 #pragma unroll
     for (int t = 0; t < NTP; t++) {
-        int e = tid + t * TPB, a = 0;
-        if (e < NT) {
-            while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
-            const int c = a + e;          // e in [0, NZ-a]: columns a..NZ
+        const int w = ACT[t * TPB + tid];
+        if (w != 0xFFFF) {
+            const int a = w & 0xFF, c = w >> 8;
             ea[t] = a; uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
             pg0[t] = oGb + 8 * (term_ix(a, 0) * G::LDG + c); pg1[t] = oGb + 8 * (term_ix(a, 1) * G::LDG + c); pg2[t] = oGb + 8 * (term_ix(a, 2) * G::LDG + c);
             pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
@@ -291,12 +314,13 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 v = fmin(fmax(v, -b + px), b - px);
             }
         }
-        X[e] = v; LAM[e] = 0.0;
+        X[e] = v; LAM[e] = 0.0; DX[e] = 0.0;     // the step is read (times a = 0) by the first merit evaluation: stale LDS may hold NaN patterns
     }
     for (int e = tid; e < N * NU; e += TPB) {
         int c = e % NU;
         double lo = lbu(c), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
         U[e] = fmin(fmax(wi[(size_t)N1 * NX + e], lo + pu), hi - pu);
+        DU[e] = 0.0;
     }
     __syncthreads();
 
@@ -700,22 +724,26 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 PROF_T(9);
                 // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
                 double mv[NTP], d0r[NTP];      // d0r: values as assembled (the owners of the control diagonals test their pivot against it)
-                {
-                    double q0[NTP], q1[NTP], q2[NTP], r0[NTP], r1[NTP], r2[NTP], hh[NTP];     // all reads first
+                // reads first, in batches of AB elements (one LDS latency per batch instead of one per element; the batch size
+                // bounds the registers held by in-flight loads)
+                constexpr int AB = 4;
+                static_for<0, (NTP + AB - 1) / AB>([&](auto bc) {
+                    constexpr int b0 = decltype(bc)::value * AB, b1 = (b0 + AB < NTP) ? b0 + AB : NTP;
+                    double q0[AB], q1[AB], q2[AB], r0[AB], r1[AB], r2[AB], hh[AB];
 #pragma unroll
-                    for (int t = 0; t < NTP; t++) {
-                        q0[t] = lds_ld(sm, pca[t], 0); q1[t] = lds_ld(sm, pca[t], 8); q2[t] = lds_ld(sm, pca[t], 16);
-                        r0[t] = lds_ld(sm, pg0[t], 0); r1[t] = lds_ld(sm, pg1[t], 0); r2[t] = lds_ld(sm, pg2[t], 0);
-                        hh[t] = lds_ld(sm, pho[t], 0);
+                    for (int t = b0; t < b1; t++) {
+                        q0[t - b0] = lds_ld(sm, pca[t], 0); q1[t - b0] = lds_ld(sm, pca[t], 8); q2[t - b0] = lds_ld(sm, pca[t], 16);
+                        r0[t - b0] = lds_ld(sm, pg0[t], 0); r1[t - b0] = lds_ld(sm, pg1[t], 0); r2[t - b0] = lds_ld(sm, pg2[t], 0);
+                        hh[t - b0] = lds_ld(sm, pho[t], 0);
                     }
 #pragma unroll
-                    for (int t = 0; t < NTP; t++) {
-                        double v = q0[t] * r0[t] + q1[t] * r1[t] + q2[t] * r2[t];
-                        v += hh[t] + dl[t] * delta;
+                    for (int t = b0; t < b1; t++) {
+                        double v = q0[t - b0] * r0[t - b0] + q1[t - b0] * r1[t - b0] + q2[t - b0] * r2[t - b0];
+                        v += hh[t - b0] + dl[t] * delta;
                         mv[t] = v;
                         d0r[t] = v;
                     }
-                }
+                });
                 PROF_T(10);
                 // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
                 // pivot test + reciprocal of pivot j: evaluated by every thread on its own slice element, meaningful on the owner
@@ -739,23 +767,20 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         else {
                             // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
                             // UR[j][a] is 0 (a < j) or annihilates the already published pivot row itself (a == j)
-                            double la[NTP], lc[NTP];
-                            static_for<0, NTP>([&](auto tc) {
-                                constexpr int t = decltype(tc)::value;
-                                if constexpr (G::slice_hi(t, TPB) > j) { la[t] = lds_ld(sm, uoa[t], 8 * j * LD); lc[t] = lds_ld(sm, uoc[t], 8 * j * LD); }
-                            });
                             if constexpr (j + 1 < NU) {
                                 constexpr int tn = G::diag_e(j + 1) / TPB;       // slice of the next pivot: update it first
-                                mv[tn] = fma(-(la[tn] * inv), lc[tn], mv[tn]);
+                                mv[tn] = fma(-(lds_ld(sm, uoa[tn], 8 * j * LD) * inv), lds_ld(sm, uoc[tn], 8 * j * LD), mv[tn]);
                                 inv_own = pivot_inv(mv[tn], d0r[tn]);
                                 static_for<0, NTP>([&](auto tc) {
                                     constexpr int t = decltype(tc)::value;
-                                    if constexpr (G::slice_hi(t, TPB) > j && t != tn) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
+                                    if constexpr (G::slice_hi(t, TPB) > j && t != tn)
+                                        mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
                                 });
                             } else {
                                 static_for<0, NTP>([&](auto tc) {
                                     constexpr int t = decltype(tc)::value;
-                                    if constexpr (G::slice_hi(t, TPB) > j) mv[t] = fma(-(la[t] * inv), lc[t], mv[t]);
+                                    if constexpr (G::slice_hi(t, TPB) > j)
+                                        mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
                                 });
                             }
                         }
@@ -1095,7 +1120,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 }
 
 // LDS bytes of one instance
-template <int M_, int THB> static size_t lds_bytes(const KParams &P)
+template <int M_, int THB> static size_t lds_bytes(const KParams &P, int tpb)
 {
     using G = G2<M_, THB>;
     const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
@@ -1103,6 +1128,7 @@ template <int M_, int THB> static size_t lds_bytes(const KParams &P)
     size_t d = N1 * G::NX * 2 + N * G::NU * 5 + N1 * G::NP * 2 + N1 * MK * 2 + N1 * G::NXB * 2 + N * M_ * 2 + W1S + W2S + G::NU + G::NX + 8;
     if (N1 * G::NX + N * G::NU > W1S) d += N1 * G::NX + N * G::NU;      // step does not fit the Riccati working area
     if (N1 * G::NX > W2S) d += N1 * G::NX;
+    d += ((size_t)((G::NT + tpb - 1) / tpb) * tpb * 2 + 7) / 8;      // 16-bit element table
     return d * sizeof(double);
 }
 
@@ -1112,7 +1138,7 @@ template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B,
     // one wave per instance up to six robots; the augmented matrix of 8 / 10 robots (860 / 1325 elements) is spread over
     // 2 / 4 waves so that the per-thread element tables stay in registers (64 threads spill to scratch there)
     constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
-    size_t lds = lds_bytes<M_, THB>(P);
+    size_t lds = lds_bytes<M_, THB>(P, TPB);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = solve_lds_kernel<M_, THB, TPB>;
     if (lds > 64 * 1024) {
