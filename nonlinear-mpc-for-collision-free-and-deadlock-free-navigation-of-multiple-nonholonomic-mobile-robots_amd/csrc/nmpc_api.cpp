@@ -40,7 +40,7 @@ void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
     c->r[0] = 0.5; c->r[1] = 0.05;
     c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
     c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
-    c->tol = 1e-8; c->mu_init = 0.1; c->max_iter = 2000;
+    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000;
 }
 
 static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)

@@ -33,7 +33,7 @@ class ProblemConfig:
     pad_rows: bool = True
     # 'ipopt' options of C6:345 that the solve honours
     tol: float = 1e-8
-    mu_init: float = 0.1
+    mu_init: float = 0.5
     max_iter: int = 2000
 
     @property

@@ -19,7 +19,7 @@ from .nlp_ref import NLPConfig
 class Opts:
     tol = 1e-8
     max_iter = 200
-    mu_init = 0.1
+    mu_init = 0.5
     mu_min = 1e-9
     kappa_eps = 10.0
     kappa_mu = 0.2

@@ -33,6 +33,7 @@
 #include "../include/nmpc.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -44,6 +45,7 @@
 
 typedef struct {
     int m, N, K, nx, nu, M, nxb, nh, thb;
+    int trace;      /* NMPC_ORACLE_TRACE=1: one line per iteration on stderr (development aid) */
     int o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;
     double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin;
     double qd[NXM], rd[NUM_], lbu[NUM_], ubu[NUM_], bxs[NXM];
@@ -76,7 +78,7 @@ void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
     c->r[0] = 0.5; c->r[1] = 0.05;
     c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
     c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
-    c->tol = 1e-8; c->mu_init = 0.1; c->max_iter = 2000;
+    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000;
 }
 
 static ws_t *ws_new(const nmpc_config_t *c)
@@ -85,6 +87,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     int m = c->m, N = c->N;
     w->m = m; w->N = N; w->K = c->n_obs; w->nx = 3 * m; w->nu = 2 * m; w->M = m * (m - 1) / 2;
     w->thb = isfinite(c->th_max) ? 1 : 0;
+    w->trace = getenv("NMPC_ORACLE_TRACE") != NULL;
     w->nxb = m * (w->thb ? 3 : 2);
     w->nh = 2 * w->nu + 2 * w->nxb + w->M + m * w->K;
     w->o_ul = 0; w->o_uu = w->nu; w->o_xl = 2 * w->nu; w->o_xu = w->o_xl + w->nxb;
@@ -617,6 +620,8 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
+        if (w->trace) fprintf(stderr, "it %3d E0 %.2e mu %.1e f %.6f th0 %.2e alpha %.3g a_p %.3g a_d %.3g delta %.2e nu %.3g dphi %.3g\n",
+                              it, kkt, mu, f, th0, alpha, a_p, a_d, delta_last, nu_pen, dphi);
         /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
         { double *t;
           t = w->X; w->X = w->Xt; w->Xt = t; t = w->U; w->U = w->Ut; w->Ut = t; t = w->S; w->S = w->St; w->St = t;

@@ -49,7 +49,7 @@ def lib():
     return _LIB
 
 
-def make_config(nlp_cfg, tol=1e-8, mu_init=0.1, max_iter=2000) -> Config:
+def make_config(nlp_cfg, tol=1e-8, mu_init=0.5, max_iter=2000) -> Config:
     """oracle.nlp_ref.NLPConfig -> nmpc_config_t."""
     c = Config()
     c.m, c.N, c.n_obs, c.pad_rows = nlp_cfg.m, nlp_cfg.N, len(nlp_cfg.obstacles), int(nlp_cfg.pad_rows)
