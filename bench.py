@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--workload", default="six", choices=["two", "six", "ten"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--max-iter", type=int, default=2000)
+    ap.add_argument("--closed-loop", type=int, default=20, help="warm closed-loop steps reported as an extra (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -150,6 +151,17 @@ def main():
                      "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
                      "note": "fp64 MFMA/VALU peak 78.6 TFLOP/s; algorithmic flops = iters*(F_kkt+F_asm) of SURVEY.md 8(d)"},
     }
+    # HBM traffic of the solve kernel: FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 --pmc passes (profiles/current,
+    # collected with tools/collect_profiles.sh on this same command, corrected as MI355X_MICROARCH.md prescribes), stored per
+    # interior-point iteration and scaled by the iterations of THIS launch; null when no pass exists for this workload
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "current", "hbm_traffic.json")))
+        if tj["workload"]["workload"] == out["config"]["workload"]:
+            out["roofline"]["traffic"] = tj["hbm_bytes_per_iteration"] * float(allst[0, 1])
+            out["roofline"]["traffic_note"] = "bytes/launch = PMC bytes per iteration (profiles/current/hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch"
+            out["roofline"]["traffic_GBps"] = out["roofline"]["traffic"] / (allst[0, 5] * 1e-3) / 1e9
+    except (OSError, KeyError, ValueError):
+        pass
     # CPU baseline: the C oracle on this box's host cores, bounded sample of the same workload
     if world == 1 and args.cpu_sample != 0:
         from oracle import oracle_lib as O
@@ -167,6 +179,32 @@ def main():
         # the GPU results of those instances agree with the oracle (same-basin fraction reported, not asserted here)
         dw = np.max(np.abs(r["x"][:n].cpu().numpy() - ref["x"]), axis=1)
         out["cpu_baseline"]["same_basin_frac_vs_gpu"] = float((dw <= 1e-6).mean())
+    # warm closed loop of SURVEY.md 8(d): 20 receding-horizon steps, each = solve + device shift/plant step (a13 + a11);
+    # and the same cold solve with HOST buffers at the boundary (H2D of p, w0 and D2H of w included).  Both are extras:
+    # `value` above is the device-resident cold solve.
+    if world == 1 and args.closed_loop > 0:
+        nx = cfg.nx
+        Pc, Wc = dP.clone(), dW0.clone()
+        its, conv = [], []
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        for _ in range(args.closed_loop):
+            rr = solver.solve_batch(Pc, Wc)
+            Wc, x0n = solver.shift_batch(Pc, rr["x"], plant=True)
+            Pc = torch.cat([x0n, Pc[:, nx:]], dim=1)
+            its.append(rr["iters"]); conv.append(rr["status"])
+        torch.cuda.synchronize(); t_cl = time.perf_counter() - t2
+        its = torch.stack(its).double().cpu().numpy(); conv = torch.stack(conv).cpu().numpy()
+        out["closed_loop"] = {"steps": args.closed_loop, "solves_per_s": B * args.closed_loop / t_cl, "ms_per_step": 1e3 * t_cl / args.closed_loop,
+                              "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
+                              "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
+                              "converged_frac": float((conv == 0).mean()),
+                              "note": "warm-started receding horizon: solve, then nmpc_shift_batch (plant step x0+T f(x0,u0) and guess shift) on device"}
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        rh = solver.solve_batch(P, W0)
+        xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()
+        t_h = time.perf_counter() - t3
+        out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
+                               "note": "same cold batch with pageable host numpy buffers at the boundary: H2D of p and w0, solve, D2H of w/status"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

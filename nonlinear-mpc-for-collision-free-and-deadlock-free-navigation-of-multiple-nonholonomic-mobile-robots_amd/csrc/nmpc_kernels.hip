@@ -315,6 +315,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     __syncthreads();
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    bool need_shift = false;
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -415,7 +416,9 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         __syncthreads();
 
         // ================= Riccati sweep with inertia correction (IPOPT alg. IC)
-        double delta = 0.0;
+        // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
+        double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
+        int ntry = 0;
         bool ok;
         for (;;) {
             ok = true;
@@ -606,12 +609,14 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             __syncthreads();
             if (tid == 0) sFail = 0;
             __syncthreads();
+            ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
             if (delta > 1e20) break;
         }
         if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;
+        need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
 
         // ================= forward sweep (serial over stages; dx_k lives in LDS)
         for (int c = tid; c < NX; c += TPB) { sX[c] = 0.0; DX[c] = 0.0; }
@@ -659,6 +664,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         }
         a_p = blk_min<TPB>(a_p, sRed);
         a_d = blk_min<TPB>(a_d, sRed);
+        a_d = fmin(a_d, a_p);      // the duals never step further than the primal variables
         __syncthreads();
 
         // ================= multipliers of the QP: adjoint recursion, serial over stages

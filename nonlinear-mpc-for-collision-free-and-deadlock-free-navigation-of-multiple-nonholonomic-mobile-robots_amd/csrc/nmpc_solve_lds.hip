@@ -469,6 +469,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     merit(0.0, f, lgs, th0, e_c, e_h);
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    bool need_shift = false;
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -665,7 +666,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         PROF_T(2);
 
         // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC)
-        double delta = 0.0;
+        // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
+        double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
+        int ntry = 0;
         bool ok;
         for (;;) {
             ok = true;
@@ -800,12 +803,14 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             }
             if (ok) break;
             __syncthreads();
+            ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
             if (delta > 1e20) break;
         }
         if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;
+        need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
         __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
         PROF_T(3);
 
@@ -909,6 +914,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             mult_max = fmax(mult_max, fabs(fb(sv, ZO[k * MK + e], ds)));
         }
         a_p = wmin<TPB>(a_p, RED); a_d = wmin<TPB>(a_d, RED);
+        a_d = fmin(a_d, a_p);      // the duals never step further than the primal variables
         PROF_T(5);
         // ============ F. multipliers of the QP: stage-parallel residuals, then the robot-local adjoint recursion in registers
         //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k) + Jx_k^T (z + dz)_k

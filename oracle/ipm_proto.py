@@ -28,7 +28,6 @@ class Opts:
     bound_push = 1e-2
     exact_hessian = True
     reg_where = 'u'       # 'all': delta*I on x and u (IPOPT); 'u': controls only; 'thu': headings and controls
-    first_trial = 'zero'  # 'zero' (IPOPT: always try delta=0 first) or 'last' (start from delta_last/3 when the previous iteration needed delta>0)
     reg_mode = 'global'   # 'global' (IPOPT alg. IC) or 'stage' (per-stage shift of Quu only)
     ls_max = 30
     eta = 1e-4
@@ -149,6 +148,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         Sx.append(sx); Su.append(su); Zx.append(mu / sx if sx.size else sx.copy()); Zu.append(mu / su if su.size else su.copy())
     lam = np.zeros((N + 1, nx))     # lam[k+1] pairs with defect c_k
     delta_last = 0.0
+    need_shift = False
     nu_pen = 1.0
     mhist = []; mh_key = None
     hist = []
@@ -249,10 +249,8 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                 Huu[k], gu[k], Hux[k] = Hu_, gu_, Hux_
 
         # --- Riccati with inertia correction
-        delta = 0.0
-        if o.first_trial == 'last' and delta_last > 0.0:
-            delta = delta_last / 3.0
-            if delta < 1e-9: delta = 0.0; delta_last = 0.0
+        # first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
+        delta = max(1e-20, 0.25 * delta_last) if need_shift else 0.0
         ntry = 0
         nsweep = 0
         while True:
@@ -303,13 +301,14 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             if delta == 0.0:
                 delta = 1e-4 if delta_last == 0.0 else max(1e-20, delta_last / 3.0)
             else:
-                delta *= 100.0 if delta_last == 0.0 and ntry <= 2 else 8.0
+                delta *= 100.0 if delta_last == 0.0 else 8.0
             if delta > 1e20:
                 break
         if not ok:
             status = 2; break
         if delta > 0:
             delta_last = delta
+        need_shift = delta > 0.0 and (ntry > 0 or delta > 1e-6)
         sweeps_total[0] += nsweep
         # forward
         dX = np.zeros((N + 1, nx)); dU = np.zeros((N, nu))
@@ -342,7 +341,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                     a = min(a, np.min(-tau * vk[neg] / dk[neg]))
             return a
         a_p = min(maxstep(Sx, dSx), maxstep(Su, dSu))
-        a_d = min(maxstep(Zx, dZx), maxstep(Zu, dZu))
+        a_d = min(maxstep(Zx, dZx), maxstep(Zu, dZu), a_p)      # the duals never step further than the primal variables
 
         # --- l1 merit backtracking
         th0 = infeas(C, Hx, Hu, Sx, Su)

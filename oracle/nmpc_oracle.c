@@ -312,7 +312,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   /* merit values of the last three iterates (same mu, nu) */
     int mcount = 0;
-    int it = 0;
+    int it = 0, need_shift = 0;
     int n_ineq = 0;
     for (int k = 0; k <= N; k++) for (int s = 0; s < nh; s++) n_ineq += slot_active(w, k, s);
     double tmp[NXM + NUM_], Jd[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
@@ -440,7 +440,9 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         }
 
         /* ---- Riccati sweep with inertia correction (IPOPT alg. IC) */
-        double delta = 0.0;
+        /* first trial: delta = 0 (IPOPT), except right after an iteration that needed a shift — then a quarter of that shift
+           is tried directly (most of those iterations fail at delta = 0 again, and a failed sweep costs ~60% of a full one) */
+        double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
         int ntry = 0, ok = 0;
         double P[NXM * NXM], pv[NXM], G[NXM * (NXM + NUM_)], Qxx[NXM * NXM], Qux[NUM_ * NXM], Quu[NUM_ * NUM_], Pb[NXM], qx[NXM], qu[NUM_];
         for (;;) {
@@ -533,6 +535,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         }
         if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;
+        need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
 
         /* ---- forward sweep */
         for (int c = 0; c < nx; c++) w->dX[c] = 0.0;
@@ -585,6 +588,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 if (dz < 0.0) a_d = fmin(a_d, -tau * w->Z[o] / dz);
             }
         }
+        a_d = fmin(a_d, a_p);      /* the duals never step further than the primal variables */
         /* ---- l1 merit backtracking */
         double th0, phi0 = barrier_and_infeas(w, f, w->C, w->H, w->S, mu, &th0);
         double dphi = 0.0;

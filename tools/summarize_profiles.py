@@ -53,6 +53,9 @@ traffic = {
     "dispatch": {"grid_x": disp[0], "workgroup_x": disp[1], "lds_bytes": disp[2], "scratch_bytes_per_lane": disp[3]},
     "registers": [{"kernel": s[0][:60], "lds_static": s[1], "scratch": s[2], "sgpr": s[3], "vgpr": s[4], "agpr": s[5]} for s in sym],
 }
+bj = json.load(open(os.path.join(src, "bench_fetch.json")))
+traffic["total_iterations_per_launch"] = bj["solve_stats"]["mean_iters"] * bj["config"]["batch_per_gpu"]
+traffic["hbm_bytes_per_iteration"] = traffic["hbm_bytes_per_launch"] / traffic["total_iterations_per_launch"]
 traffic["hbm_GBps"] = traffic["hbm_bytes_per_launch"] / (solve[3] * 1e-9) / 1e9
 json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 sq = counters("sq")
