@@ -664,7 +664,6 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         }
         a_p = blk_min<TPB>(a_p, sRed);
         a_d = blk_min<TPB>(a_d, sRed);
-        a_d = fmin(a_d, a_p);      // the duals never step further than the primal variables
         __syncthreads();
 
         // ================= multipliers of the QP: adjoint recursion, serial over stages
@@ -750,6 +749,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
+        a_d = fmin(a_d, alpha);      // the duals never step further than the primal variables actually moved
         __syncthreads();
         // ================= accept: primal / slack step alpha, dual step a_d with safeguard (IPOPT eq. 16)
         for (int e = tid; e < (N + 1) * NX; e += TPB) {

@@ -914,7 +914,6 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             mult_max = fmax(mult_max, fabs(fb(sv, ZO[k * MK + e], ds)));
         }
         a_p = wmin<TPB>(a_p, RED); a_d = wmin<TPB>(a_d, RED);
-        a_d = fmin(a_d, a_p);      // the duals never step further than the primal variables
         PROF_T(5);
         // ============ F. multipliers of the QP: stage-parallel residuals, then the robot-local adjoint recursion in registers
         //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k) + Jx_k^T (z + dz)_k
@@ -1045,6 +1044,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if ((ft - mu * lgt) + nu_pen * tht <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
+        // the duals never step further than the primal variables actually moved: a dual step taken
+        // without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks
+        a_d = fmin(a_d, alpha);
         PROF_T(6);
 #ifdef NMPC_PROFILE
         if (prof_out && tid == 0 && (int)inst == P.trace_inst && iter < 2040) {

@@ -341,7 +341,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                     a = min(a, np.min(-tau * vk[neg] / dk[neg]))
             return a
         a_p = min(maxstep(Sx, dSx), maxstep(Su, dSu))
-        a_d = min(maxstep(Zx, dZx), maxstep(Zu, dZu), a_p)      # the duals never step further than the primal variables
+        a_d = min(maxstep(Zx, dZx), maxstep(Zu, dZu))
 
         # --- l1 merit backtracking
         th0 = infeas(C, Hx, Hu, Sx, Su)
@@ -383,7 +383,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         if o.verbose:
             print("     alpha %.3g a_p %.3g a_d %.3g nu %.3g dphi %.3g th0 %.3g ntry %d" % (alpha, a_p, a_d, nu_pen, dphi, th0, ntry))
         X, U, Sx, Su = Xn, Un, Sxn, Sun
-        a_dual = a_d
+        a_dual = min(a_d, alpha)      # the duals never step further than the primal variables actually moved
         for k in range(N + 1):
             Zx[k] = Zx[k] + a_dual * dZx[k]; Zu[k] = Zu[k] + a_dual * dZu[k]
             # IPOPT eq. (16) safeguard

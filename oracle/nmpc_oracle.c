@@ -588,7 +588,6 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 if (dz < 0.0) a_d = fmin(a_d, -tau * w->Z[o] / dz);
             }
         }
-        a_d = fmin(a_d, a_p);      /* the duals never step further than the primal variables */
         /* ---- l1 merit backtracking */
         double th0, phi0 = barrier_and_infeas(w, f, w->C, w->H, w->S, mu, &th0);
         double dphi = 0.0;
@@ -626,6 +625,9 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         }
         if (w->trace) fprintf(stderr, "it %3d E0 %.2e mu %.1e f %.6f th0 %.2e alpha %.3g a_p %.3g a_d %.3g delta %.2e nu %.3g dphi %.3g\n",
                               it, kkt, mu, f, th0, alpha, a_p, a_d, delta_last, nu_pen, dphi);
+        /* the duals never step further than the primal variables actually moved: a dual step taken
+           without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks */
+        a_d = fmin(a_d, alpha);
         /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
         { double *t;
           t = w->X; w->X = w->Xt; w->Xt = t; t = w->U; w->U = w->Ut; w->Ut = t; t = w->S; w->S = w->St; w->St = t;

@@ -80,6 +80,29 @@ def test_warm_start_matches_oracle(built):
     assert (dw <= W_TOL).mean() >= 0.85, dw
 
 
+def test_closed_loop_steps_match_oracle(built):
+    """8 receding-horizon steps (solve -> device plant step + shift, a9/a13/a11): at every step the HIP path and the oracle
+    get the SAME (p, guess) — the oracle's closed loop drives both, so basin differences cannot accumulate — and must agree
+    on status, iterate (W_TOL) and on the shifted guess / next state bit-for-bit-level (1e-12)."""
+    import torch
+    ocfg = R.cfg_six(20)
+    B = 48
+    P, W = Hh.batch(ocfg, B, 2)
+    P = P.copy()
+    oc = O.make_config(ocfg, max_iter=600)
+    s = _solver(ocfg, B)
+    for step in range(8):
+        ref = O.solve_batch(oc, P, W)
+        r = _np(s.solve_batch(P, W)); torch.cuda.synchronize()
+        assert (ref["status"] == 0).all() and (r["status"] == 0).all(), (step, ref["status"], r["status"])
+        dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+        assert (dw <= W_TOL).mean() >= 0.85, (step, dw)
+        Wn, x0n = O.shift_batch(oc, P, ref["x"])
+        wn_d, x0n_d = s.shift_batch(P, ref["x"], plant=True)
+        assert np.abs(wn_d.cpu().numpy() - Wn).max() <= 1e-12 and np.abs(x0n_d.cpu().numpy() - x0n).max() <= 1e-12
+        P[:, : ocfg.nx] = x0n; W = Wn
+
+
 def _composite_cfg(N=25, seed=7):
     """BASELINE.json config 5 (synthetic composite, no reference script): six-robot pair rows + 8 circular obstacles."""
     rng = np.random.default_rng(seed)
