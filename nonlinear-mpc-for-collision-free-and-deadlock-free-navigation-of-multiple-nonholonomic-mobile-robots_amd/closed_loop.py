@@ -1,0 +1,124 @@
+"""Batched receding-horizon episodes: the reference's main loop run for B swarms at once.
+
+Mirrors, per swarm and per control period (file:line of the reference):
+  p = [x0; xs]                                   AllScripts/casadi_test.py:145            (C6:419)
+  sol = solver(x0=guess, p=p, ...)               casadi_test.py:153                       (C6:432)
+  x0 <- x0 + T f(x0, u[0]) ; guess <- shift      casadi_test.py:17-26,170,180             (C6:450,465)
+  stop when ||x0 - xs|| <= tol                   casadi_test.py:143 (5e-2)
+  goal sequencing: next goal when ||x - xs|| < tol   AllScripts/centralized_one_robots_implementation.py:176-188,236-239 (0.075)
+
+Every arithmetic step runs in libnmpc_hip.so (nmpc_solve_batch, nmpc_shift_batch); the bookkeeping around it (norms,
+goal indices, distance statistics) is a handful of torch reductions on device memory.  As in the reference, the control of a
+non-converged solve is applied as returned; such solves are counted in `failed_solves`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .solver import NmpcSolver
+
+
+@dataclass
+class EpisodeResult:
+    steps: int                    # control periods executed
+    arrived: "np.ndarray"         # [B] bool: last goal reached within tol
+    arrival_step: "np.ndarray"    # [B] int: period at which it happened (-1: never)
+    collision_free: "np.ndarray"  # [B] bool: all pair distances >= dmin - coll_tol (and obstacle clearances) at every period
+    min_pair_distance: "np.ndarray"   # [B] smallest centre distance seen (inf for one robot)
+    deadlocked: "np.ndarray"      # [B] bool: not arrived and the swarm moved less than move_tol over the last `window` periods
+    final_error: "np.ndarray"     # [B] ||x - xs|| at the end
+    failed_solves: int            # solves that did not return status 0
+    total_solves: int
+    mean_iters_by_step: "np.ndarray"   # [steps]
+    states: Optional["np.ndarray"] = None   # [steps+1, B, n_x] when keep_states
+
+
+def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol: float = 5e-2, coll_tol: float = 1e-6,
+                         window: int = 10, move_tol: float = 1e-3, keep_states: bool = False) -> EpisodeResult:
+    """Run B closed-loop episodes.  x0: [B, n_x]; goals: [B, n_x] or [B, G, n_x] (visited in order)."""
+    torch = solver.torch
+    cfg = solver.cfg
+    nx, m = cfg.nx, cfg.m
+    dev = solver.device
+    x = solver._dev(x0, (-1, nx)).clone()
+    B = x.shape[0]
+    g = torch.as_tensor(np.asarray(goals, dtype=np.float64) if not torch.is_tensor(goals) else goals, dtype=torch.float64, device=dev)
+    if g.dim() == 2:
+        g = g[:, None, :]
+    if g.shape[0] != B or g.shape[2] != nx:
+        raise ValueError(f"goals must be [B, n_x] or [B, G, n_x] with B={B}, n_x={nx}; got {tuple(g.shape)}")
+    G = g.shape[1]
+    gi = torch.zeros(B, dtype=torch.long, device=dev)
+    ar = torch.arange(B, device=dev)
+    # cold start of C6:398-400: states replicated, controls zero
+    w = torch.cat([x.repeat(1, cfg.N + 1), torch.zeros((B, cfg.N * cfg.nu), dtype=torch.float64, device=dev)], dim=1)
+    arrived = torch.zeros(B, dtype=torch.bool, device=dev)
+    arrival = torch.full((B,), -1, dtype=torch.long, device=dev)
+    mind = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+    clear = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+    iu = torch.triu_indices(m, m, 1, device=dev)
+    obs = torch.tensor(cfg.obstacles, dtype=torch.float64, device=dev).reshape(-1, 3) if len(cfg.obstacles) else None
+    hist, its, states = [], [], []
+    failed = total = 0
+
+    def track(xc):
+        nonlocal mind, clear
+        xy = xc.reshape(B, m, 3)[:, :, :2]
+        if m > 1:
+            d = (xy[:, iu[0]] - xy[:, iu[1]]).norm(dim=2).min(dim=1).values
+            mind = torch.minimum(mind, d)
+        if obs is not None:
+            c = ((xy[:, :, None, :] - obs[None, None, :, :2]).norm(dim=3) - cfg.rob_dim - obs[None, None, :, 2]).amin(dim=(1, 2))
+            clear = torch.minimum(clear, c)
+
+    track(x)
+    if keep_states:
+        states.append(x.clone())
+    steps = 0
+    for step in range(max_steps):
+        xs = g[ar, gi]
+        err = (x - xs).norm(dim=1)
+        hit = (err <= stop_tol) & ~arrived
+        last = gi == G - 1
+        newly = hit & last
+        arrival = torch.where(newly, torch.full_like(arrival, step), arrival)
+        arrived |= newly
+        gi = torch.where(hit & ~last, gi + 1, gi)
+        if bool(arrived.all()):
+            break
+        xs = g[ar, gi]
+        p = torch.cat([x, xs], dim=1)
+        r = solver.solve_batch(p, w)
+        total += B
+        failed += int((r["status"] != 0).sum())
+        its.append(r["iters"].double().mean())
+        w, xn = solver.shift_batch(p, r["x"], plant=True)
+        # a swarm that has arrived keeps solving (its problem is the fixed point) but stays where it is
+        x = torch.where(arrived[:, None], x, xn)
+        track(x)
+        hist.append(x.clone())
+        if len(hist) > window:
+            hist.pop(0)
+        if keep_states:
+            states.append(x.clone())
+        steps += 1
+    xs = g[ar, gi]
+    err = (x - xs).norm(dim=1)
+    late = (err <= stop_tol) & (gi == G - 1) & ~arrived
+    arrival = torch.where(late, torch.full_like(arrival, steps), arrival)
+    arrived |= late
+    moved = (hist[-1] - hist[0]).norm(dim=1) if len(hist) > 1 else torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+    dead = ~arrived & (moved < move_tol)
+    ok = torch.ones(B, dtype=torch.bool, device=dev)
+    if m > 1:
+        ok &= mind >= cfg.dmin - coll_tol
+    if obs is not None:
+        ok &= clear >= cfg.margin - coll_tol
+    return EpisodeResult(steps=steps, arrived=arrived.cpu().numpy(), arrival_step=arrival.cpu().numpy(), collision_free=ok.cpu().numpy(),
+                         min_pair_distance=mind.cpu().numpy(), deadlocked=dead.cpu().numpy(), final_error=err.cpu().numpy(),
+                         failed_solves=failed, total_solves=total,
+                         mean_iters_by_step=torch.stack(its).cpu().numpy() if its else np.zeros(0),
+                         states=torch.stack(states).cpu().numpy() if keep_states else None)

@@ -40,3 +40,37 @@ def to_product_cfg(ocfg, **kw):
     return nmpc_amd.ProblemConfig(m=ocfg.m, N=ocfg.N, T=ocfg.T, dmin=ocfg.dmin, q=tuple(ocfg.q), r=tuple(ocfg.r), v_max=ocfg.v_max,
                                   w_max=ocfg.w_max, xy_max=ocfg.xy_max, th_max=ocfg.th_max, obstacles=list(ocfg.obstacles),
                                   rob_dim=ocfg.rob_dim, margin=ocfg.margin, pad_value=ocfg.pad_value, pad_rows=ocfg.pad_rows, **kw)
+
+
+def closed_loop_oracle(ocfg, x0, goals, max_steps, stop_tol=5e-2, max_iter=2000):
+    """The reference's main loop (casadi_test.py:143-183; goal sequencing of centralized_one_robots_implementation.py:176-239)
+    driven by the CPU oracle — checker for nmpc_amd.simulate_closed_loop."""
+    from oracle import oracle_lib as O
+    oc = O.make_config(ocfg, max_iter=max_iter)
+    x = np.array(x0, dtype=np.float64); B, nx = x.shape
+    g = np.array(goals, dtype=np.float64)
+    if g.ndim == 2:
+        g = g[:, None, :]
+    G = g.shape[1]
+    gi = np.zeros(B, dtype=int); ar = np.arange(B)
+    w = np.stack([R.cold_start(ocfg, xi) for xi in x])
+    arrived = np.zeros(B, dtype=bool); arrival = np.full(B, -1)
+    states = [x.copy()]
+    steps = 0
+    for step in range(max_steps):
+        err = np.linalg.norm(x - g[ar, gi], axis=1)
+        hit = (err <= stop_tol) & ~arrived
+        last = gi == G - 1
+        arrival[hit & last] = step; arrived |= hit & last
+        gi = np.where(hit & ~last, gi + 1, gi)
+        if arrived.all():
+            break
+        p = np.concatenate([x, g[ar, gi]], axis=1)
+        r = O.solve_batch(oc, p, w)
+        w, xn = O.shift_batch(oc, p, r["x"])
+        x = np.where(arrived[:, None], x, xn)
+        states.append(x.copy()); steps += 1
+    err = np.linalg.norm(x - g[ar, gi], axis=1)
+    late = (err <= stop_tol) & (gi == G - 1) & ~arrived
+    arrival[late] = steps; arrived |= late
+    return dict(steps=steps, arrived=arrived, arrival_step=arrival, final_error=err, states=np.stack(states))
