@@ -50,7 +50,7 @@ extern "C" {
  */
 typedef struct nmpc_config {
     int32_t m;              /* robots, 1..NMPC_MAX_ROBOTS                                       */
-    int32_t N;              /* horizon                                                          */
+    int32_t N;              /* horizon, 2..4096                                                 */
     int32_t n_obs;          /* static circular obstacles, 0..NMPC_MAX_OBSTACLES                 */
     int32_t pad_rows;       /* 1: initial g block carries M constant rows (C6:278); 0: it does not */
     double T;               /* sample time                                                      */

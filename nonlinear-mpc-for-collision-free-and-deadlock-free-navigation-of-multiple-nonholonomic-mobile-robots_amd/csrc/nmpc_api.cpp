@@ -115,8 +115,9 @@ int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 
 int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                          int32_t *iters, double *kkt, void *stream)
 {
-    if (!h || !p || !w0 || !w_out || B < 0 || B > h->max_batch) return NMPC_E_ARG;
-    if (B == 0) return NMPC_OK;
+    if (!h || B < 0 || B > h->max_batch) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;      /* empty batch: nothing to read or write, pointers may be null */
+    if (!p || !w0 || !w_out) return NMPC_E_ARG;
     hipError_t e = (h->kernel == 1)
                        ? nmpc::launch_solve(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                        : nmpc::launch_solve_lds(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
@@ -125,17 +126,19 @@ int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const dou
 
 int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream)
 {
-    if (!h || !p || !w || B < 0) return NMPC_E_ARG;
+    if (!h || B < 0) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;
+    if (!p || !w) return NMPC_E_ARG;
     hipError_t e = nmpc::launch_eval(h->P, h->cfg.m, B, p, w, f, g, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
 int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const double *w_in, double *w_next, double *x0_next, void *stream)
 {
-    if (!h || !w_in || !w_next || w_in == w_next || B < 0) return NMPC_E_ARG;
-    if (x0_next && !p_in) return NMPC_E_ARG;
+    if (!h || B < 0) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;
+    if (!w_in || !w_next || w_in == w_next) return NMPC_E_ARG;
+    if (x0_next && !p_in) return NMPC_E_ARG;
     hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }

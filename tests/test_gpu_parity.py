@@ -238,3 +238,39 @@ def test_reference_call_surface(built):
         solver(x0=args['x0'], p=args['p'], lbx=args['lbx'] * 2)
     with pytest.raises(ValueError):
         solver(x0=args['x0'][:-1], p=args['p'])
+
+
+def test_edge_cases(built):
+    """empty batch, batch larger than the handle, iteration limit 0, shortest and longest horizons, maximum obstacle count."""
+    import torch
+    import nmpc_amd
+    # empty batch: a no-op that returns empty outputs; over-sized batch: ValueError from the host, NMPC_E_ARG from the C ABI
+    ocfg = R.cfg_two(20)
+    s = _solver(ocfg, 4)
+    r = s.solve_batch(np.zeros((0, 2 * ocfg.nx)), np.zeros((0, ocfg.n_var)))
+    assert r["x"].shape == (0, ocfg.n_var) and r["status"].shape == (0,)
+    P, W0 = Hh.batch(ocfg, 8, 1)
+    with pytest.raises(ValueError):
+        s.solve_batch(P, W0)
+    dp, dw = torch.as_tensor(P, device="cuda"), torch.as_tensor(W0, device="cuda")
+    out = torch.empty_like(dw)
+    assert s.lib.nmpc_solve_batch(s._h, 8, dp.data_ptr(), dw.data_ptr(), out.data_ptr(), None, None, None, None, None) == -1      # NMPC_E_ARG
+    # max_iter = 0: status 1, the (interior-projected) guess comes back, x0 pinned
+    s0 = _solver(ocfg, 4, max_iter=0)
+    r0 = _np(s0.solve_batch(P[:4], W0[:4]))
+    ref0 = O.solve_batch(O.make_config(ocfg, max_iter=0), P[:4], W0[:4])
+    assert (r0["status"] == 1).all() and (r0["iters"] == 0).all()
+    assert np.abs(r0["x"] - ref0["x"]).max() <= 1e-15 and np.allclose(r0["kkt"], ref0["kkt"], rtol=1e-12)
+    # horizons 2 (the minimum the ABI accepts) and 60 (LDS 141 KB per instance at m=6), eight obstacles around one robot (NMPC_MAX_OBSTACLES)
+    ring = [(0.9 * np.cos(a), 0.9 * np.sin(a), 0.15) for a in np.linspace(0, 2 * np.pi, 8, endpoint=False)]
+    c1 = R.cfg_one(20); c1.obstacles = ring; c1.rob_dim = 0.2; c1.margin = 0.05
+    for name, cfg, B, idx in (("two_N2", R.cfg_two(2), 8, 1), ("six_N60", R.cfg_six(60), 4, 2), ("one_K8", c1, 8, 0)):
+        Pb, Wb = Hh.batch(cfg, B, idx)
+        if name == "one_K8":      # start in the middle of the ring, goals outside
+            Pb[:, :3] = np.array([0.0, 0.0, 0.3]); Pb[:, 3:5] = 1.6 * Pb[:, 3:5] / np.linalg.norm(Pb[:, 3:5], axis=1, keepdims=True)
+            Wb = np.stack([R.cold_start(cfg, p[:3]) for p in Pb])
+        rr = _np(_solver(cfg, B, max_iter=600).solve_batch(Pb, Wb)); torch.cuda.synchronize()
+        ref = O.solve_batch(O.make_config(cfg, max_iter=600), Pb, Wb)
+        assert (rr["status"] == ref["status"]).all() and (rr["status"] == 0).all(), (name, rr["status"], ref["status"])
+        dw_ = np.max(np.abs(rr["x"] - ref["x"]), axis=1)
+        assert (dw_ <= W_TOL).mean() >= 0.75, (name, dw_)
