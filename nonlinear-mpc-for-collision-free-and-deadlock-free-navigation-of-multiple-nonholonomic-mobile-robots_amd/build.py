@@ -29,7 +29,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + SOURCES
+    cmd = [_hipcc(), "--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", "-shared", "-o", SO] + SOURCES
     if os.environ.get("NMPC_PROFILE"):
         cmd.insert(1, "-DNMPC_PROFILE")
     if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30

@@ -22,3 +22,6 @@ bad = np.where(r["status"] != 0)[0]
 print("non-converged:", bad[:10], "kkt", r["kkt"][bad[:10]], "oracle iters", ref["iters"][bad[:10]])
 d = np.where(r["iters"] != ref["iters"])[0]
 print("first differing:", d[:10], r["iters"][d[:10]], ref["iters"][d[:10]])
+same = dw <= 1e-6
+df = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
+print("objective: max rel diff on same-basin instances %.2e, n > 1e-6: %d" % (df[same].max() if same.any() else 0.0, int((df[same] > 1e-6).sum())))
