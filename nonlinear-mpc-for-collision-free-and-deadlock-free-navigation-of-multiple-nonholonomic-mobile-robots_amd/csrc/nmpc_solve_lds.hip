@@ -117,6 +117,14 @@ __device__ __forceinline__ double rcp_nr(double d)
 
 template <int M_> __device__ __forceinline__ int pidx(int a, int b) { return a * (2 * M_ - a - 1) / 2 + (b - a - 1); }
 
+// A value every lane of the wave holds identically (a finished reduction, an LDS word read at a wave-uniform address),
+// moved through v_readfirstlane: the compiler then KNOWS it is wave-uniform, so the branches that depend on it (line-search
+// acceptance, convergence, pivot failure, barrier update) become scalar branches instead of exec-masked divergent regions.
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 template <int TPB> __device__ __forceinline__ double wsum(double v, double *red)
 {
 #pragma unroll
@@ -129,7 +137,7 @@ template <int TPB> __device__ __forceinline__ double wsum(double v, double *red)
         for (int w = 0; w < TPB / 64; w++) t += red[w];
         v = t;
     }
-    return v;
+    return uniform_f64(v);
 }
 template <int TPB> __device__ __forceinline__ double wmax(double v, double *red)
 {
@@ -143,7 +151,7 @@ template <int TPB> __device__ __forceinline__ double wmax(double v, double *red)
         for (int w = 1; w < TPB / 64; w++) t = fmax(t, red[w]);
         v = t;
     }
-    return v;
+    return uniform_f64(v);
 }
 template <int TPB> __device__ __forceinline__ double wmin(double v, double *red) { return -wmax<TPB>(-v, red); }
 
@@ -259,37 +267,6 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         ACT[t * TPB + tid] = w;
     }
     __syncthreads();
-    // ---- per-element LDS byte offsets (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries,
-    //      the coefficient triple and the Hessian addition of the assembly; the mirror positions of the Schur block
-    int ea[NTP], uoa[NTP], uoc[NTP], pg0[NTP], pg1[NTP], pg2[NTP], pca[NTP], pho[NTP], wa1[NTP], wa2[NTP];
-    double dl[NTP];
-#pragma unroll
-    for (int t = 0; t < NTP; t++) {
-        const int w = ACT[t * TPB + tid];
-        if (w != 0xFFFF) {
-            const int a = w & 0xFF, c = w >> 8;
-            ea[t] = a; uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
-            pg0[t] = oGb + 8 * (term_ix(a, 0) * G::LDG + c); pg1[t] = oGb + 8 * (term_ix(a, 1) * G::LDG + c); pg2[t] = oGb + 8 * (term_ix(a, 2) * G::LDG + c);
-            pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
-            dl[t] = (c == a && a < NU) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
-            int h = G::PK_ZERO;
-            if (c == NZ) h = G::PK_G + a;
-            else if (c == a) h = G::PK_HD + a;
-            else if (a < NU) { if (!(a & 1) && c == NU + 3 * (a >> 1) + 2) h = G::PK_HVT + (a >> 1); }
-            else {
-                int sa = a - NU, sc = c - NU, ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
-                if (da < 2 && dc < 2) h = (ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc);
-            }
-            pho[t] = oPK + 8 * h;
-            if (a >= NU) {
-                if (c == NZ) { wa1[t] = oPf + 8 * (NX * NX + (a - NU)); wa2[t] = wa1[t]; }                  // PV follows Pf
-                else { wa1[t] = oPf + 8 * ((a - NU) * NX + (c - NU)); wa2[t] = oPf + 8 * ((c - NU) * NX + (a - NU)); }
-            } else { wa1[t] = oPf; wa2[t] = oPf; }
-        } else {
-            ea[t] = -1; uoa[t] = oUR; uoc[t] = oUR; pg0[t] = oGb; pg1[t] = oGb; pg2[t] = oGb; pca[t] = oPK + 8 * G::PK_CF; pho[t] = oPK + 8 * G::PK_ZERO;
-            dl[t] = 0.0; wa1[t] = oPf; wa2[t] = oPf;
-        }
-    }
     // the strictly lower part of the pivot-row buffer stays zero for the whole solve: the branch-free rank-1 update
     // multiplies by UR[j][a], which must vanish for rows a < j that are already eliminated
     for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
@@ -681,6 +658,37 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 }
                 for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
             }
+            // ---- per-element LDS byte offsets (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries,
+            //      the coefficient triple and the Hessian addition of the assembly; the mirror positions of the Schur block
+            int ea[NTP], uoa[NTP], uoc[NTP], pg0[NTP], pg1[NTP], pg2[NTP], pca[NTP], pho[NTP], wa1[NTP], wa2[NTP];
+            double dl[NTP];
+        #pragma unroll
+            for (int t = 0; t < NTP; t++) {
+                const int w = ACT[t * TPB + tid];
+                if (w != 0xFFFF) {
+                    const int a = w & 0xFF, c = w >> 8;
+                    ea[t] = a; uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
+                    pg0[t] = oGb + 8 * (term_ix(a, 0) * G::LDG + c); pg1[t] = oGb + 8 * (term_ix(a, 1) * G::LDG + c); pg2[t] = oGb + 8 * (term_ix(a, 2) * G::LDG + c);
+                    pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
+                    dl[t] = (c == a && a < NU) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
+                    int h = G::PK_ZERO;
+                    if (c == NZ) h = G::PK_G + a;
+                    else if (c == a) h = G::PK_HD + a;
+                    else if (a < NU) { if (!(a & 1) && c == NU + 3 * (a >> 1) + 2) h = G::PK_HVT + (a >> 1); }
+                    else {
+                        int sa = a - NU, sc = c - NU, ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
+                        if (da < 2 && dc < 2) h = (ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc);
+                    }
+                    pho[t] = oPK + 8 * h;
+                    if (a >= NU) {
+                        if (c == NZ) { wa1[t] = oPf + 8 * (NX * NX + (a - NU)); wa2[t] = wa1[t]; }                  // PV follows Pf
+                        else { wa1[t] = oPf + 8 * ((a - NU) * NX + (c - NU)); wa2[t] = oPf + 8 * ((c - NU) * NX + (a - NU)); }
+                    } else { wa1[t] = oPf; wa2[t] = oPf; }
+                } else {
+                    ea[t] = -1; uoa[t] = oUR; uoc[t] = oUR; pg0[t] = oGb; pg1[t] = oGb; pg2[t] = oGb; pca[t] = oPK + 8 * G::PK_CF; pho[t] = oPK + 8 * G::PK_ZERO;
+                    dl[t] = 0.0; wa1[t] = oPf; wa2[t] = oPf;
+                }
+            }
             // the pivot-row area doubles as staging / residual storage between sweeps: restore the zero lower part the
             // select-free rank-1 update relies on
             for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
@@ -765,7 +773,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         });
                         if (ea[td] == j && dl[td] != 0.0) INV[j] = inv_own;
                         lds_sync<TPB>();
-                        const double inv = INV[j];
+                        const double inv = uniform_f64(INV[j]);
                         if (!(inv > 0.0)) ok = false;
                         else {
                             // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
