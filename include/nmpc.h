@@ -119,6 +119,16 @@ int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const doub
 int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const double *w_in, double *w_next,
                          double *x0_next, void *stream);
 
+/*
+ * Odometry front-end of the scripts' callbacks (AS/centralized_two_robots_implementation.py:18-37): for n robots,
+ *   odom [n][4] = (x_r, y_r, q_z, q_w) wheel-odometry pose in the robot's own start frame (q_w is carried but, as in the
+ *                  reference, not used: yaw = 2 asin(q_z)),
+ *   init [n][3] = (x_init, y_init, th_init) pose of that start frame in the global frame,
+ *   pose [n][3] = (x, y, phi) in the global frame: [x y] = R(th_init) [x_r y_r] + [x_init y_init], phi = 2 asin(q_z) + th_init.
+ * Device pointers; no handle (pure function of its inputs).  SURVEY.md 8(f) row 3.
+ */
+int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, void *stream);
+
 /* library / kernel identification string (build flags, arch) */
 const char *nmpc_version(void);
 

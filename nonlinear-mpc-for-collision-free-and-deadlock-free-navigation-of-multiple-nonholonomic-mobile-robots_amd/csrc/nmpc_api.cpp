@@ -143,6 +143,16 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
+int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, void *stream)
+{
+    if (n < 0) return NMPC_E_ARG;
+    if (n == 0) return NMPC_OK;
+    if (!odom || !init || !pose) return NMPC_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;
+    return nmpc::launch_odometry((long)n, odom, init, pose, (hipStream_t)stream) == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
 /* development aid (not part of include/nmpc.h): per-phase cycle counters of an NMPC_PROFILE build */
 int32_t nmpc_debug_profile(nmpc_handle_t *h, int64_t *out12, int32_t reset)
 {

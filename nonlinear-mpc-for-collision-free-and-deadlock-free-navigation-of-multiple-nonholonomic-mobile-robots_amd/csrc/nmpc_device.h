@@ -29,5 +29,6 @@ hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, con
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);
+hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, hipStream_t st);
 
 }  // namespace nmpc

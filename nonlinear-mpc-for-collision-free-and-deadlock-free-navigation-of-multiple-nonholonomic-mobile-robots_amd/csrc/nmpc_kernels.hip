@@ -893,6 +893,27 @@ template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, cons
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Odometry front-end (C2:18-37): per robot, wheel-odometry pose in the robot's start frame -> pose in the global frame.
+//   th = 2 asin(q_z); phi = th + th_init; [x y] = R(th_init) [x_r y_r] + [x_init y_init].   Streaming, 7 doubles in, 3 out.
+__global__ __launch_bounds__(256) void odometry_kernel(long n, const double *__restrict__ odom, const double *__restrict__ init, double *__restrict__ pose)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double xr = odom[4 * i], yr = odom[4 * i + 1], qz = odom[4 * i + 2];
+    const double xi = init[3 * i], yi = init[3 * i + 1], thi = init[3 * i + 2];
+    double s, c;
+    sincos(thi, &s, &c);
+    pose[3 * i] = (c * xr - s * yr) + xi;
+    pose[3 * i + 1] = (s * xr + c * yr) + yi;
+    pose[3 * i + 2] = 2.0 * asin(qz) + thi;
+}
+hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, hipStream_t st)
+{
+    hipLaunchKernelGGL(odometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, odom, init, pose);
+    return hipGetLastError();
+}
+
 #define NMPC_DISPATCH(M, CALL)                                                                                                    \
     switch (M) {                                                                                                                  \
     case 1: return CALL(1);                                                                                                       \

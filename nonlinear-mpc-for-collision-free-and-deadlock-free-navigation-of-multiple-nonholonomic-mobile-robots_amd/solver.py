@@ -46,6 +46,40 @@ def cold_start(cfg: ProblemConfig, x0) -> np.ndarray:
     return np.concatenate([np.tile(x0, cfg.N + 1), np.zeros(cfg.nu * cfg.N)])
 
 
+def odometry_to_global(odom, init, device=None):
+    """Batched odometry callback of the scripts (C2:18-37): odom [n,4] = (x_r, y_r, q_z, q_w), init [n,3] = (x, y, th) of the
+    robot's start frame -> pose [n,3] in the global frame (device tensor).  Runs nmpc_odometry_batch."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    o = torch.as_tensor(odom, dtype=torch.float64, device=dev).reshape(-1, 4).contiguous()
+    i0 = torch.as_tensor(init, dtype=torch.float64, device=dev).reshape(-1, 3).contiguous()
+    if o.shape[0] != i0.shape[0]:
+        raise ValueError(f"odom has {o.shape[0]} rows, init {i0.shape[0]}")
+    pose = torch.empty((o.shape[0], 3), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nmpc_odometry_batch(o.shape[0], o.data_ptr(), i0.data_ptr(), pose.data_ptr(), torch.cuda.current_stream().cuda_stream), "nmpc_odometry_batch")
+    return pose
+
+
+def split_swarm(p, m: int):
+    """Independent-robot mode (AS/mpc_online_casadi_tb3_1.py et al. run one 3-state NLP per robot):
+    p [B, 6m] = [x0 (3m); xs (3m)] of B swarms -> p1 [B*m, 6] of B*m single-robot problems (robot-major inside a swarm).
+    Solve those with a ProblemConfig(m=1) solver; merge_swarm() puts the single-robot plans back side by side."""
+    p = np.asarray(p, dtype=np.float64).reshape(-1, 6 * m)
+    B = p.shape[0]
+    return np.concatenate([p[:, : 3 * m].reshape(B, m, 3), p[:, 3 * m:].reshape(B, m, 3)], axis=2).reshape(B * m, 6)
+
+
+def merge_swarm(w1, m: int, N: int):
+    """w1 [B*m, 3(N+1)+2N] single-robot solutions -> w [B, (3m)(N+1)+(2m)N] in the centralized packing (C6:339)."""
+    w1 = np.asarray(w1, dtype=np.float64)
+    B = w1.shape[0] // m
+    X = w1[:, : 3 * (N + 1)].reshape(B, m, N + 1, 3).transpose(0, 2, 1, 3).reshape(B, -1)
+    U = w1[:, 3 * (N + 1):].reshape(B, m, N, 2).transpose(0, 2, 1, 3).reshape(B, -1)
+    return np.concatenate([X, U], axis=1)
+
+
 class NmpcSolver:
     """The object nlpsol() returns.  Owns a device workspace sized for `max_batch` instances."""
 

@@ -321,3 +321,14 @@ C6_START = np.array([0.7, 0.4, -2.618, 0.0, 0.8, -1.57, -0.7, 0.4, -0.523,
                      -0.7, -0.4, 0.523, 0.0, -0.8, 1.57, 0.7, -0.4, 2.618])  # C6:364-369
 C6_GOAL = np.array([-0.7, -0.4, -2.618, 0.0, -0.8, -1.57, 0.7, -0.4, -0.523,
                     0.7, 0.4, 0.523, 0.0, 0.8, 1.57, -0.7, 0.4, 2.618])      # C6:386-388
+
+
+def odom_to_global(odom, init):
+    """Odometry callbacks of the scripts (C2:18-37): odom [n,4] = (x_r, y_r, q_z, q_w) in the robot's start frame,
+    init [n,3] = (x_init, y_init, th_init) -> pose [n,3] in the global frame.  q_w is not used by the reference either."""
+    odom = np.asarray(odom, dtype=np.float64).reshape(-1, 4); init = np.asarray(init, dtype=np.float64).reshape(-1, 3)
+    th = 2.0 * np.arcsin(odom[:, 2])
+    c, s = np.cos(init[:, 2]), np.sin(init[:, 2])
+    x = (c * odom[:, 0] - s * odom[:, 1]) + init[:, 0]
+    y = (s * odom[:, 0] + c * odom[:, 1]) + init[:, 1]
+    return np.stack([x, y, th + init[:, 2]], axis=1)

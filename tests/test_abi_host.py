@@ -121,3 +121,21 @@ def test_gather_results_gloo_world2(tmp_path):
            "--master-port", "29617", str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_independent_robot_mode_packing(built):
+    """B swarms of m robots <-> B*m single-robot problems; without pair rows the centralized objective
+    is the sum of the single-robot objectives and the packing round-trips."""
+    import nmpc_amd
+    m, N, B = 3, 5, 4
+    rng = np.random.default_rng(3)
+    p = rng.normal(size=(B, 6 * m))
+    p1 = nmpc_amd.split_swarm(p, m)
+    assert p1.shape == (B * m, 6)
+    assert np.array_equal(p1[1], np.concatenate([p[0, 3:6], p[0, 3 * m + 3: 3 * m + 6]]))
+    w1 = rng.normal(size=(B * m, 3 * (N + 1) + 2 * N))
+    w = nmpc_amd.merge_swarm(w1, m, N)
+    c1 = R.cfg_one(N); cm = R.cfg_one(N); cm.m = m
+    for b in range(B):
+        f_sum = sum(R.objective(c1, w1[b * m + i], p1[b * m + i]) for i in range(m))
+        assert abs(R.objective(cm, w[b], p[b]) - f_sum) <= 1e-12 * max(1.0, abs(f_sum))

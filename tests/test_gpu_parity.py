@@ -274,3 +274,20 @@ def test_edge_cases(built):
         assert (rr["status"] == ref["status"]).all() and (rr["status"] == 0).all(), (name, rr["status"], ref["status"])
         dw_ = np.max(np.abs(rr["x"] - ref["x"]), axis=1)
         assert (dw_ <= W_TOL).mean() >= 0.75, (name, dw_)
+
+
+def test_odometry_front_end(built):
+    """SURVEY 8(f) row 3, C2:18-37: quaternion -> yaw and start-frame -> global-frame transform, batched; empty and large n."""
+    import nmpc_amd
+    rng = np.random.Generator(np.random.PCG64(Hh.SEED0 + 5))
+    for n in (0, 1, 6, 100003):
+        odom = np.concatenate([rng.uniform(-3, 3, (n, 2)), rng.uniform(-1, 1, (n, 1)), rng.uniform(-1, 1, (n, 1))], axis=1)
+        init = np.concatenate([rng.uniform(-2, 2, (n, 2)), rng.uniform(-np.pi, np.pi, (n, 1))], axis=1)
+        got = nmpc_amd.odometry_to_global(odom, init).cpu().numpy()
+        ref = R.odom_to_global(odom, init)
+        assert got.shape == (n, 3)
+        if n:
+            assert np.abs(got - ref).max() <= 1e-14, np.abs(got - ref).max()
+    # the literal first callback: robot 1 of the two-robot script starts at (-0.7112, -0.7112, 0.785) (C2:213-216)
+    pose = nmpc_amd.odometry_to_global([[0.1, 0.0, np.sin(0.2 / 2), np.cos(0.2 / 2)]], [R.C2_START[:3]]).cpu().numpy()[0]
+    assert np.allclose(pose, [R.C2_START[0] + 0.1 * np.cos(0.785), R.C2_START[1] + 0.1 * np.sin(0.785), 0.985], atol=1e-15)

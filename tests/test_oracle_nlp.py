@@ -113,3 +113,11 @@ def test_c_eval_and_shift_match_numpy(name):
         np.testing.assert_array_equal(wn[b], R.pack(c, R.shift_states(c, X), R.shift(c.T, 0.0, U)[1]))
         np.testing.assert_allclose(x0n[b], R.plant_step(c, P[b, : c.nx], U[0]), atol=1e-15)
     assert O.lib().nmpc_n_var(cc) == c.n_var and O.lib().nmpc_n_g(cc) == c.n_g
+
+
+def test_odometry_known_answers():
+    """C2:18-37: identity start frame leaves the position alone; a quarter-turn start frame maps x_r onto +y."""
+    p = R.odom_to_global([[0.3, -0.2, 0.0, 1.0]], [[0.0, 0.0, 0.0]])[0]
+    assert np.allclose(p, [0.3, -0.2, 0.0], atol=1e-16)
+    p = R.odom_to_global([[1.0, 0.0, np.sin(np.pi / 8), np.cos(np.pi / 8)]], [[2.0, 3.0, np.pi / 2]])[0]
+    assert np.allclose(p, [2.0, 4.0, np.pi / 4 + np.pi / 2], atol=1e-15)
