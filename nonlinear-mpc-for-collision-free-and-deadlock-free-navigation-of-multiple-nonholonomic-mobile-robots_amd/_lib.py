@@ -12,7 +12,7 @@ NMPC_MAX_ROBOTS = 10
 NMPC_MAX_OBSTACLES = 8
 
 STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Error_In_Step_Computation",
-                3: "Infeasible_Problem_Detected"}
+                3: "Infeasible_Problem_Detected", 4: "Restoration_Failed"}
 ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMPC_E_NOMEM"}
 
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_destroy",

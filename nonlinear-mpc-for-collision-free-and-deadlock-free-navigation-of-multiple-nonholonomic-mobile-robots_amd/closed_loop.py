@@ -37,8 +37,15 @@ class EpisodeResult:
 
 
 def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol: float = 5e-2, coll_tol: float = 1e-6,
-                         window: int = 10, move_tol: float = 1e-3, keep_states: bool = False) -> EpisodeResult:
-    """Run B closed-loop episodes.  x0: [B, n_x]; goals: [B, n_x] or [B, G, n_x] (visited in order)."""
+                         window: int = 10, move_tol: float = 1e-3, keep_states: bool = False,
+                         on_failure: str = "apply") -> EpisodeResult:
+    """Run B closed-loop episodes.  x0: [B, n_x]; goals: [B, n_x] or [B, G, n_x] (visited in order).
+
+    on_failure: what a swarm does in a period whose solve did not converge (status != 0; ~1 in 1e5 warm solves stall at an
+    infeasible stationary point): "apply" = the reference's behaviour, the returned iterate's first control is applied;
+    "previous_plan" = the next control of the previous period's plan (the shifted guess) is applied instead."""
+    if on_failure not in ("apply", "previous_plan"):
+        raise ValueError("on_failure must be 'apply' or 'previous_plan'")
     torch = solver.torch
     cfg = solver.cfg
     nx, m = cfg.nx, cfg.m
@@ -95,7 +102,8 @@ def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol
         total += B
         failed += int((r["status"] != 0).sum())
         its.append(r["iters"].double().mean())
-        w, xn = solver.shift_batch(p, r["x"], plant=True)
+        plan = r["x"] if on_failure == "apply" else torch.where((r["status"] == 0)[:, None], r["x"], w)
+        w, xn = solver.shift_batch(p, plan, plant=True)
         # a swarm that has arrived keeps solving (its problem is the fixed point) but stays where it is
         x = torch.where(arrived[:, None], x, xn)
         track(x)

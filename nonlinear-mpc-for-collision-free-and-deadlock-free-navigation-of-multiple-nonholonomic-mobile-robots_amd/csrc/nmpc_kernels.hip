@@ -316,6 +316,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     bool need_shift = false;
+    int n_tiny = 0;      // consecutive iterations with a step length below 1e-10 (stall -> NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -750,6 +751,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             if (ls < 29) alpha *= 0.5;
         }
         a_d = fmin(a_d, alpha);      // the duals never step further than the primal variables actually moved
+        n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
         __syncthreads();
         // ================= accept: primal / slack step alpha, dual step a_d with safeguard (IPOPT eq. 16)
         for (int e = tid; e < (N + 1) * NX; e += TPB) {
@@ -770,6 +772,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         f = eval_point();
         __syncthreads();
         iter++;
+        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
     }
 
     // ---- write back sol['x'] = [vec(X); vec(U)] (C6:436,440)

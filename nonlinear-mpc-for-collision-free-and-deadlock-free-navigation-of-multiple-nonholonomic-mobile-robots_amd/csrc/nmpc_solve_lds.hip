@@ -447,6 +447,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     bool need_shift = false;
+    int n_tiny = 0;      // consecutive iterations with a step length below 1e-10 (stall -> NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -1055,6 +1056,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         // the duals never step further than the primal variables actually moved: a dual step taken
         // without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks
         a_d = fmin(a_d, alpha);
+        n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
         PROF_T(6);
 #ifdef NMPC_PROFILE
         if (prof_out && tid == 0 && (int)inst == P.trace_inst && iter < 2040) {
@@ -1119,6 +1121,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         f = ft; lgs = lgt; th0 = tht; e_c = ect; e_h = eht;
         iter++;
         PROF_T(8);
+        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
     }
 
     __syncthreads();

@@ -149,6 +149,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
     lam = np.zeros((N + 1, nx))     # lam[k+1] pairs with defect c_k
     delta_last = 0.0
     need_shift = False
+    n_tiny = 0
     nu_pen = 1.0
     mhist = []; mh_key = None
     hist = []
@@ -393,6 +394,9 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                 Zu[k] = np.clip(Zu[k], mu / (1e10 * Su[k]), 1e10 * mu / Su[k])
         lam = lam + alpha * (lamn - lam)
         it += 1
+        n_tiny = n_tiny + 1 if alpha < 1e-10 else 0
+        if n_tiny >= 5:
+            status = 4; break      # stalled: converging to an infeasible stationary point
 
     wout = np.concatenate([X.reshape(-1), U.reshape(-1)])
     fval = float(np.sum(qd * (X[:N] - xs) ** 2) + np.sum(rd * U * U))

@@ -312,7 +312,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   /* merit values of the last three iterates (same mu, nu) */
     int mcount = 0;
-    int it = 0, need_shift = 0;
+    int it = 0, need_shift = 0, n_tiny = 0;
     int n_ineq = 0;
     for (int k = 0; k <= N; k++) for (int s = 0; s < nh; s++) n_ineq += slot_active(w, k, s);
     double tmp[NXM + NUM_], Jd[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
@@ -628,6 +628,9 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         /* the duals never step further than the primal variables actually moved: a dual step taken
            without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks */
         a_d = fmin(a_d, alpha);
+        /* stall: the search direction is blocked (slacks pinned at zero with the infeasibility not decreasing) — the iterate
+           is converging to an infeasible stationary point; IPOPT would enter restoration here, this solver reports it */
+        n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
         /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
         { double *t;
           t = w->X; w->X = w->Xt; w->Xt = t; t = w->U; w->U = w->Ut; w->Ut = t; t = w->S; w->S = w->St; w->St = t;
@@ -644,6 +647,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 }
         for (size_t i = nx; i < (size_t)(N + 1) * nx; i++) w->lam[i] += alpha * (w->lamn[i] - w->lam[i]);
         it++;
+        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
     }
     memcpy(wout, w->X, sizeof(double) * (size_t)(N + 1) * nx);
     memcpy(wout + (size_t)(N + 1) * nx, w->U, sizeof(double) * (size_t)N * nu);

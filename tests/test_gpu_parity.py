@@ -291,3 +291,18 @@ def test_odometry_front_end(built):
     # the literal first callback: robot 1 of the two-robot script starts at (-0.7112, -0.7112, 0.785) (C2:213-216)
     pose = nmpc_amd.odometry_to_global([[0.1, 0.0, np.sin(0.2 / 2), np.cos(0.2 / 2)]], [R.C2_START[:3]]).cpu().numpy()[0]
     assert np.allclose(pose, [R.C2_START[0] + 0.1 * np.cos(0.785), R.C2_START[1] + 0.1 * np.sin(0.785), 0.985], atol=1e-15)
+
+
+def test_stalled_solve_reports_status_4(built):
+    """tests/golden/stall_case.npz: a warm-started six-robot solve captured from a closed-loop soak (step 67 of swarm 260,
+    tools/soak_failures.py) that converges to an infeasible stationary point (theta stuck at 1.07, slacks pinned at zero).
+    IPOPT would switch to restoration; both implementations stop after 5 consecutive steps below 1e-10 with
+    NMPC_STATUS_STALLED instead of burning max_iter iterations (one such instance used to hold a 4096-batch for 0.4 s)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
+    ocfg = R.cfg_six(20)
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"][None], d["w"][None])
+    r = _np(_solver(ocfg, 1, max_iter=2000).solve_batch(d["p"][None], d["w"][None]))
+    assert ref["status"][0] == 4 and r["status"][0] == 4, (ref["status"], r["status"])
+    assert ref["iters"][0] < 200 and abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 5
+    assert abs(r["kkt"][0] - ref["kkt"][0]) <= 1e-3 * ref["kkt"][0]

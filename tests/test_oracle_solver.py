@@ -115,3 +115,10 @@ def test_closed_loop_episode_stays_collision_free_and_converged():
                 assert (np.linalg.norm(xy[:, i] - xy[:, j], axis=1) >= cfg.dmin - 1e-6).all()
     d1 = np.linalg.norm((P[:, : cfg.nx] - P[:, cfg.nx:]).reshape(48, 6, 3)[:, :, :2], axis=2).sum(axis=1)
     assert (d1 < d0).all()
+
+
+def test_stall_case_is_reported_not_iterated_to_the_limit():
+    """the captured infeasible-stationary-point case (see tests/test_gpu_parity.py::test_stalled_solve_reports_status_4)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
+    r = O.solve_batch(O.make_config(R.cfg_six(20), max_iter=2000), d["p"][None], d["w"][None])
+    assert r["status"][0] == 4 and r["iters"][0] < 200 and r["kkt"][0] > 1e-3
