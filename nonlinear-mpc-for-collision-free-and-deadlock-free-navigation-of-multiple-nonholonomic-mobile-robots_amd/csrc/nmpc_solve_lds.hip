@@ -1151,12 +1151,9 @@ template <int M_, int THB> static size_t lds_bytes(const KParams &P, int tpb)
     return d * sizeof(double);
 }
 
-template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
-                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+template <int M_, int THB, int TPB> static hipError_t launch2_mtt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
+                                                                  int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
-    // one wave per instance up to six robots; the augmented matrix of 8 / 10 robots (860 / 1325 elements) is spread over
-    // 2 / 4 waves so that the per-thread element tables stay in registers (64 threads spill to scratch there)
-    constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
     size_t lds = lds_bytes<M_, THB>(P, TPB);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = solve_lds_kernel<M_, THB, TPB>;
@@ -1166,6 +1163,23 @@ template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B,
     }
     hipLaunchKernelGGL(kern, dim3(B), dim3(TPB), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
     return hipGetLastError();
+}
+
+template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
+                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+{
+    // Throughput shape: one wave per instance up to six robots (4 instances per CU, 1024 resident on the chip); the augmented
+    // matrix of 8 / 10 robots (860 / 1325 elements) is spread over 2 / 4 waves so that the per-thread element tables stay in
+    // registers (64 threads spill to scratch there).
+    // Latency shape (five and six robots): a batch that leaves most of the chip idle is solved with 2 or 4 waves per instance —
+    // measured 189 / 148 / 139 us per iteration at 64 / 128 / 256 threads (m=6, N=20, one instance per CU).  This is the
+    // reference's own use (one swarm per control period) and the tail of small closed-loop batches.
+    if constexpr (M_ == 5 || M_ == 6) {
+        if (B <= 256) return launch2_mtt<M_, THB, 256>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+        if (B <= 512) return launch2_mtt<M_, THB, 128>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    }
+    constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
+    return launch2_mtt<M_, THB, TPB>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
 }
 template <int M_> static hipError_t launch2_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                                               int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
