@@ -275,6 +275,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     const bool gact = tid < HG * NZ;
     const int gx0 = term_ix(gcol, 0), gx1 = term_ix(gcol, 1), gx2 = term_ix(gcol, 2);
     constexpr int GRPT = (NX + HG - 1) / HG;                                   // rows per thread in the G pass
+    constexpr int PBP = (64 / NX >= 3) ? 3 : (64 / NX >= 2 ? 2 : 1), PBC = (NX + PBP - 1) / PBP;   // parts / columns per part of the P b product
+    static_assert(PBP * PBC == NX, "P b split must be exact");
     const int gpb0 = oPf + 8 * (grow0 * NX + gx0), gpb1 = oPf + 8 * (grow0 * NX + gx1), gpb2 = oPf + 8 * (grow0 * NX + gx2);
     const int gwb = oGb + 8 * (grow0 * G::LDG + gcol);
 
@@ -721,16 +723,23 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         if ((NX % HG == 0) || grow0 + n * HG < NX) lds_st(sm, gwb, 8 * n * HG * G::LDG, c0 * p0[n] + c1 * p1[n] + c2 * p2[n]);
                     });
                 }
-                for (int r = tid; r < NX; r += TPB) {
-                    double a0 = PV[r], a1 = 0.0, a2 = 0.0;
-                    const int pr = oPf + 8 * r * NX;
+                // last column p + P b (b = -c_k): the NX dot products are split into PBP column parts over PBP * NX lanes of the
+                // first wave and recombined with two lane shuffles (was: NX lanes doing NX serial LDS reads each)
+                if (tid < 64) {
+                    const int pr_ = tid % NX, part = tid / NX;
+                    double a = 0.0;
+                    if (part < PBP) {
+                        const int pb = oPf + 8 * (pr_ * NX + part * PBC), cb = oPK + 8 * (G::PK_C + part * PBC);
+                        double pq[PBC], cq[PBC];
 #pragma unroll
-                    for (int c = 0; c + 2 < NX; c += 3) {
-                        a0 = fma(-lds_ld(sm, pr, 8 * c), PK[G::PK_C + c], a0);
-                        a1 = fma(-lds_ld(sm, pr, 8 * (c + 1)), PK[G::PK_C + c + 1], a1);
-                        a2 = fma(-lds_ld(sm, pr, 8 * (c + 2)), PK[G::PK_C + c + 2], a2);
+                        for (int c = 0; c < PBC; c++) { pq[c] = lds_ld(sm, pb, 8 * c); cq[c] = lds_ld(sm, cb, 8 * c); }
+#pragma unroll
+                        for (int c = 0; c < PBC; c++) a = fma(-pq[c], cq[c], a);
                     }
-                    Gb[r * G::LDG + NZ] = a0 + (a1 + a2);
+                    double ssum = a;
+                    if constexpr (PBP >= 2) ssum += __shfl(a, tid + NX);
+                    if constexpr (PBP >= 3) ssum += __shfl(a, tid + 2 * NX);
+                    if (tid < NX) Gb[tid * G::LDG + NZ] = PV[tid] + ssum;
                 }
                 lds_sync<TPB>();
                 PROF_T(9);
