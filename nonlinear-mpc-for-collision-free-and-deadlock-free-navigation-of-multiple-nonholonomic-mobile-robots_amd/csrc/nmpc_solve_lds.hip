@@ -667,30 +667,33 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double dl[NTP];
         #pragma unroll
             for (int t = 0; t < NTP; t++) {
+                // branch-free decode (selects only): this runs at the start of every sweep
                 const int w = ACT[t * TPB + tid];
-                if (w != 0xFFFF) {
-                    const int a = w & 0xFF, c = w >> 8;
-                    ea[t] = a; uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
-                    pg0[t] = oGb + 8 * (term_ix(a, 0) * G::LDG + c); pg1[t] = oGb + 8 * (term_ix(a, 1) * G::LDG + c); pg2[t] = oGb + 8 * (term_ix(a, 2) * G::LDG + c);
-                    pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
-                    dl[t] = (c == a && a < NU) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
-                    int h = G::PK_ZERO;
-                    if (c == NZ) h = G::PK_G + a;
-                    else if (c == a) h = G::PK_HD + a;
-                    else if (a < NU) { if (!(a & 1) && c == NU + 3 * (a >> 1) + 2) h = G::PK_HVT + (a >> 1); }
-                    else {
-                        int sa = a - NU, sc = c - NU, ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
-                        if (da < 2 && dc < 2) h = (ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc);
-                    }
-                    pho[t] = oPK + 8 * h;
-                    if (a >= NU) {
-                        if (c == NZ) { wa1[t] = oPf + 8 * (NX * NX + (a - NU)); wa2[t] = wa1[t]; }                  // PV follows Pf
-                        else { wa1[t] = oPf + 8 * ((a - NU) * NX + (c - NU)); wa2[t] = oPf + 8 * ((c - NU) * NX + (a - NU)); }
-                    } else { wa1[t] = oPf; wa2[t] = oPf; }
-                } else {
-                    ea[t] = -1; uoa[t] = oUR; uoc[t] = oUR; pg0[t] = oGb; pg1[t] = oGb; pg2[t] = oGb; pca[t] = oPK + 8 * G::PK_CF; pho[t] = oPK + 8 * G::PK_ZERO;
-                    dl[t] = 0.0; wa1[t] = oPf; wa2[t] = oPf;
-                }
+                const bool valid = w != 0xFFFF;
+                const int a = valid ? (w & 0xFF) : 0, c = valid ? (w >> 8) : 0;
+                const bool au = a < NU, odd = (a & 1) != 0, rhs = c == NZ;
+                const int iu = a >> 1;                                          // robot of a control row
+                const int sa = au ? 0 : a - NU, sc = (c < NU || rhs) ? 0 : c - NU;   // state indices of row / column (0 when not a state)
+                const int ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
+                // state index of term t of row/column a of [B A] (term_ix)
+                const int ix0 = au ? (odd ? 3 * iu + 2 : 3 * iu) : sa;
+                const int ix1 = au ? (odd ? 3 * iu + 2 : 3 * iu + 1) : (da < 2 ? sa : 3 * ia);
+                const int ix2 = au ? (odd ? 3 * iu + 2 : 3 * iu) : (da < 2 ? sa : 3 * ia + 1);
+                ea[t] = valid ? a : -1;
+                uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
+                pg0[t] = oGb + 8 * (ix0 * G::LDG + c); pg1[t] = oGb + 8 * (ix1 * G::LDG + c); pg2[t] = oGb + 8 * (ix2 * G::LDG + c);
+                pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
+                dl[t] = (valid && c == a && au) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
+                // Hessian addition: lowest priority first, later selects override
+                int h = G::PK_ZERO;
+                h = (!au && !rhs && c >= NU && da < 2 && dc < 2) ? ((ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc)) : h;
+                h = (au && !odd && c == NU + 3 * iu + 2) ? (G::PK_HVT + iu) : h;
+                h = (c == a) ? (G::PK_HD + a) : h;
+                h = rhs ? (G::PK_G + a) : h;
+                pho[t] = oPK + 8 * (valid ? h : G::PK_ZERO);
+                // mirror positions of the Schur block [P | p] (state rows only; PV follows Pf)
+                const int w1 = au ? 0 : (rhs ? NX * NX + sa : sa * NX + sc), w2 = au ? 0 : (rhs ? NX * NX + sa : sc * NX + sa);
+                wa1[t] = oPf + 8 * w1; wa2[t] = oPf + 8 * w2;
             }
             // the pivot-row area doubles as staging / residual storage between sweeps: restore the zero lower part the
             // select-free rank-1 update relies on
