@@ -306,3 +306,35 @@ def test_stalled_solve_reports_status_4(built):
     assert ref["status"][0] == 4 and r["status"][0] == 4, (ref["status"], r["status"])
     assert ref["iters"][0] < 200 and abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 5
     assert abs(r["kkt"][0] - ref["kkt"][0]) <= 1e-3 * ref["kkt"][0]
+
+
+def test_random_configurations_match_oracle(built):
+    """differential fuzz (tools/fuzz_configs.py, 40 configurations: 100 % status-equal / same-basin): robots, horizon, sample
+    time, weights, bounds, obstacle count and the heading bound drawn at random; every configuration must agree with the
+    oracle on status (>= 90 % of its instances), iterate (>= 80 % same basin), objective and KKT error."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(Hh.SEED0 + 404))
+    for t in range(14):
+        m = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10]))
+        N = int(rng.integers(2, 41)) if m <= 6 else int(rng.integers(2, 25))
+        K = int(rng.integers(0, 9)) if m <= 3 else int(rng.integers(0, 3))
+        cfg = R.NLPConfig(m=m, N=N, T=float(rng.uniform(0.05, 0.3)), dmin=float(rng.uniform(0.15, 0.4)),
+                          q=tuple(rng.uniform(0.1, 5.0, 3)), r=tuple(rng.uniform(0.02, 1.0, 2)),
+                          v_max=float(rng.uniform(0.1, 0.5)), w_max=float(rng.uniform(1.0, 3.0)), xy_max=float(rng.uniform(4.0, 10.0)),
+                          th_max=float(rng.choice([np.inf, 2 * np.pi, 4.0])), rob_dim=0.2, margin=float(rng.uniform(0.05, 0.1)),
+                          obstacles=[(float(x), float(y), float(r_)) for x, y, r_ in
+                                     zip(rng.uniform(-1.5, 1.5, K), rng.uniform(-1.5, 1.5, K), rng.uniform(0.1, 0.2, K))],
+                          pad_rows=bool(m > 1))
+        B = 16 if m <= 6 else 6
+        P = np.stack([Hh.instance(rng, cfg) for _ in range(B)])
+        W0 = np.stack([R.cold_start(cfg, p[: cfg.nx]) for p in P])
+        ref = O.solve_batch(O.make_config(cfg, max_iter=800), P, W0)
+        r = _np(_solver(cfg, B, max_iter=800).solve_batch(P, W0)); torch.cuda.synchronize()
+        dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+        same = dw <= W_TOL
+        tag = (t, m, N, K, cfg.th_max)
+        assert (r["status"] == ref["status"]).mean() >= 0.9, (tag, r["status"], ref["status"])
+        assert same.mean() >= 0.8, (tag, dw)
+        rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
+        assert (rel[same] <= F_RTOL).all(), (tag, rel)
+        assert (r["kkt"][r["status"] == 0] <= 1e-8).all(), tag
