@@ -90,6 +90,8 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     h->max_batch = max_batch;
     const char *kv = getenv("NMPC_KERNEL");
     h->kernel = (kv && kv[0] == '1') ? 1 : 2;
+    // horizons whose iterate does not fit the 160 KB of LDS of a CU run on the HBM-resident kernel (same algorithm, slower)
+    if (h->kernel == 2 && nmpc::lds_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 1;
     nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
     int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
     h->ws_bytes = (int64_t)sizeof(double) * per * max_batch;

@@ -26,6 +26,7 @@ hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const d
                         int32_t *iters, double *kkt, double *ws, hipStream_t st);
 hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                             int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
+size_t lds_kernel_bytes(const KParams &P, int m);
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);

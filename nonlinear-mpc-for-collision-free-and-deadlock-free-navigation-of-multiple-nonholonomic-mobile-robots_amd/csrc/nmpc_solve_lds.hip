@@ -1216,6 +1216,18 @@ hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, con
     }
 }
 
+// LDS bytes one instance of the LDS-resident kernel needs in its throughput shape (0 if m is not supported); the C ABI falls
+// back to the HBM-resident kernel when this exceeds the 160 KB of a CU
+size_t lds_kernel_bytes(const KParams &P, int m)
+{
+#define LB(M, T) case M: return P.thb ? lds_bytes<M, 1>(P, T) : lds_bytes<M, 0>(P, T);
+    switch (m) {
+        LB(1, 64) LB(2, 64) LB(3, 64) LB(4, 64) LB(5, 64) LB(6, 64) LB(8, 128) LB(10, 256)
+    default: return 0;
+    }
+#undef LB
+}
+
 // workspace doubles per instance for this kernel (packs + transposed gains)
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride)
 {

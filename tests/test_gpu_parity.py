@@ -264,7 +264,8 @@ def test_edge_cases(built):
     # horizons 2 (the minimum the ABI accepts) and 60 (LDS 141 KB per instance at m=6), eight obstacles around one robot (NMPC_MAX_OBSTACLES)
     ring = [(0.9 * np.cos(a), 0.9 * np.sin(a), 0.15) for a in np.linspace(0, 2 * np.pi, 8, endpoint=False)]
     c1 = R.cfg_one(20); c1.obstacles = ring; c1.rob_dim = 0.2; c1.margin = 0.05
-    for name, cfg, B, idx in (("two_N2", R.cfg_two(2), 8, 1), ("six_N60", R.cfg_six(60), 4, 2), ("one_K8", c1, 8, 0)):
+    # ten robots over 60 stages need 218 KB per instance: the C ABI falls back to the HBM-resident kernel by itself
+    for name, cfg, B, idx in (("two_N2", R.cfg_two(2), 8, 1), ("six_N60", R.cfg_six(60), 4, 2), ("one_K8", c1, 8, 0), ("ten_N60", R.cfg_ten(60), 2, 3)):
         Pb, Wb = Hh.batch(cfg, B, idx)
         if name == "one_K8":      # start in the middle of the ring, goals outside
             Pb[:, :3] = np.array([0.0, 0.0, 0.3]); Pb[:, 3:5] = 1.6 * Pb[:, 3:5] / np.linalg.norm(Pb[:, 3:5], axis=1, keepdims=True)
@@ -273,7 +274,7 @@ def test_edge_cases(built):
         ref = O.solve_batch(O.make_config(cfg, max_iter=600), Pb, Wb)
         assert (rr["status"] == ref["status"]).all() and (rr["status"] == 0).all(), (name, rr["status"], ref["status"])
         dw_ = np.max(np.abs(rr["x"] - ref["x"]), axis=1)
-        assert (dw_ <= W_TOL).mean() >= 0.75, (name, dw_)
+        assert (dw_ <= W_TOL).mean() >= (0.5 if name == "ten_N60" else 0.75), (name, dw_)      # ten_N60: 2 long, chaotic solves
 
 
 def test_odometry_front_end(built):
