@@ -305,18 +305,22 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     double mu = P.mu_init;
     double f = eval_point();
     __syncthreads();
-    for (int e = tid; e < (N + 1) * NH; e += TPB) {
-        int k = e / NH, s = e - k * NH;
-        if (!slot_active(P, k, s)) { S[e] = 1.0; Z[e] = 0.0; continue; }
-        double fl = (s < P.o_xl) ? 1e-12 : bp;
-        double sv = fmax(H[e], fl);
-        S[e] = sv; Z[e] = mu / sv;
-    }
-    __syncthreads();
+    // slacks and duals from the constraint values H of the current point (also the barrier restart after a stall)
+    auto init_barrier = [&]() {
+        for (int e = tid; e < (N + 1) * NH; e += TPB) {
+            int k = e / NH, s = e - k * NH;
+            if (!slot_active(P, k, s)) { S[e] = 1.0; Z[e] = 0.0; continue; }
+            double fl = (s < P.o_xl) ? 1e-12 : bp;
+            double sv = fmax(H[e], fl);
+            S[e] = sv; Z[e] = mu / sv;
+        }
+        __syncthreads();
+    };
+    init_barrier();
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     bool need_shift = false;
-    int n_tiny = 0;      // consecutive iterations with a step length below 1e-10 (stall -> NMPC_STATUS_STALLED)
+    int n_tiny = 0, n_restart = 0;      // consecutive iterations with a step length below 1e-10 (stall -> restart, then NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -772,7 +776,29 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         f = eval_point();
         __syncthreads();
         iter++;
-        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
+        if (n_tiny >= 5) {
+            if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+            // barrier restart from the current primal point (restoration in miniature, see the oracle)
+            n_restart++; n_tiny = 0;
+            mu = fmax(mu, P.mu_init);
+            for (int e = tid + NX; e < (N + 1) * NX; e += TPB) {
+                const int d = (e % NX) % 3;
+                if (d < 2 || P.thb) {
+                    double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                    X[e] = fmin(fmax(X[e], -b + px), b - px);
+                }
+                LAM[e] = 0.0;
+            }
+            for (int e = tid; e < N * NU; e += TPB) {
+                double lo = lbu(P, e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+                U[e] = fmin(fmax(U[e], lo + pu), hi - pu);
+            }
+            __syncthreads();
+            f = eval_point();
+            __syncthreads();
+            init_barrier();
+            delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0;
+        }
     }
 
     // ---- write back sol['x'] = [vec(X); vec(U)] (C6:436,440)

@@ -411,45 +411,48 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double mu = P.mu_init;
     trig();
     __syncthreads();
-    // ---- slacks and duals
-    for (int it = tid; it < N1 * NP; it += TPB) {
-        int k = it / NPd, q = it - k * NP;
-        if (k >= 1 && k <= N - 1) {
-            int i, j; pair_ij(q, i, j);
-            double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-            double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
-            SPp[it] = sv; ZPp[it] = mu / sv;
-        } else { SPp[it] = 1.0; ZPp[it] = 0.0; }
-    }
-    for (int it = tid; it < N1 * MK; it += TPB) {
-        int k = it / MK, e = it - k * MK;
-        if (k >= 1 && k <= N - 1) {
-            int i = e / K, o = e - i * K;
-            double dx = X[k * NX + 3 * i] - P.obs[3 * o], dy = X[k * NX + 3 * i + 1] - P.obs[3 * o + 1];
-            double sv = fmax(h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin), bp);
-            SO[it] = sv; ZO[it] = mu / sv;
-        } else { SO[it] = 1.0; ZO[it] = 0.0; }
-    }
-    for (int e = tid; e < N * NU; e += TPB) {
-        int c = e % NU;
-        double lo = lbu(c);
-        double sl = fmax(U[e] - lo, 1e-12), su = fmax(-lo - U[e], 1e-12);
-        SUL[e] = sl; SUU[e] = su; ZUL[e] = mu / sl; ZUU[e] = mu / su;
-    }
-    for (int e = tid; e < N1 * NXB; e += TPB) {
-        int k = e / NXB, s = e - k * NXB;
-        if (k >= 1) {
-            double v = X[k * NX + bst(s)], b = bvl(s), sl = fmax(v + b, bp), su = fmax(b - v, bp);
-            ZXL[e] = mu / sl; ZXU[e] = mu / su;
-        } else { ZXL[e] = 0.0; ZXU[e] = 0.0; }
-    }
-    __syncthreads();
+    // ---- slacks and duals from the current primal point (also the barrier restart after a stall)
+    auto init_barrier = [&]() {
+        for (int it = tid; it < N1 * NP; it += TPB) {
+            int k = it / NPd, q = it - k * NP;
+            if (k >= 1 && k <= N - 1) {
+                int i, j; pair_ij(q, i, j);
+                double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
+                double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
+                SPp[it] = sv; ZPp[it] = mu / sv;
+            } else { SPp[it] = 1.0; ZPp[it] = 0.0; }
+        }
+        for (int it = tid; it < N1 * MK; it += TPB) {
+            int k = it / MK, e = it - k * MK;
+            if (k >= 1 && k <= N - 1) {
+                int i = e / K, o = e - i * K;
+                double dx = X[k * NX + 3 * i] - P.obs[3 * o], dy = X[k * NX + 3 * i + 1] - P.obs[3 * o + 1];
+                double sv = fmax(h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin), bp);
+                SO[it] = sv; ZO[it] = mu / sv;
+            } else { SO[it] = 1.0; ZO[it] = 0.0; }
+        }
+        for (int e = tid; e < N * NU; e += TPB) {
+            int c = e % NU;
+            double lo = lbu(c);
+            double sl = fmax(U[e] - lo, 1e-12), su = fmax(-lo - U[e], 1e-12);
+            SUL[e] = sl; SUU[e] = su; ZUL[e] = mu / sl; ZUU[e] = mu / su;
+        }
+        for (int e = tid; e < N1 * NXB; e += TPB) {
+            int k = e / NXB, s = e - k * NXB;
+            if (k >= 1) {
+                double v = X[k * NX + bst(s)], b = bvl(s), sl = fmax(v + b, bp), su = fmax(b - v, bp);
+                ZXL[e] = mu / sl; ZXU[e] = mu / su;
+            } else { ZXL[e] = 0.0; ZXU[e] = 0.0; }
+        }
+        __syncthreads();
+    };
+    init_barrier();
     double f, lgs, th0, e_c, e_h;
     merit(0.0, f, lgs, th0, e_c, e_h);
 
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     bool need_shift = false;
-    int n_tiny = 0;      // consecutive iterations with a step length below 1e-10 (stall -> NMPC_STATUS_STALLED)
+    int n_tiny = 0, n_restart = 0;      // consecutive iterations with a step length below 1e-10 (stall -> restart, then NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
@@ -1133,7 +1136,32 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         f = ft; lgs = lgt; th0 = tht; e_c = ect; e_h = eht;
         iter++;
         PROF_T(8);
-        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
+        if (n_tiny >= 5) {
+            if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+            // barrier restart from the current primal point (restoration in miniature, see the oracle)
+            n_restart++; n_tiny = 0;
+            mu = fmax(mu, P.mu_init);
+            // the primal point goes back strictly inside the simple bounds first (a control sitting on its bound would restart
+            // with a slack of ~1e-6 and a dual of mu / 1e-6)
+            for (int e = tid + NX; e < N1 * NX; e += TPB) {
+                const int d = (e % NX) % 3;
+                if (d < 2 || THB) {
+                    double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                    X[e] = fmin(fmax(X[e], -b + px), b - px);
+                }
+                LAM[e] = 0.0;
+            }
+            for (int e = tid; e < N * NU; e += TPB) {
+                double lo = lbu(e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+                U[e] = fmin(fmax(U[e], lo + pu), hi - pu);
+            }
+            __syncthreads();
+            trig();
+            __syncthreads();
+            init_barrier();
+            merit(0.0, f, lgs, th0, e_c, e_h);
+            delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0;
+        }
     }
 
     __syncthreads();

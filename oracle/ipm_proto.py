@@ -150,6 +150,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
     delta_last = 0.0
     need_shift = False
     n_tiny = 0
+    n_restart = 0
     nu_pen = 1.0
     mhist = []; mh_key = None
     hist = []
@@ -396,7 +397,21 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         it += 1
         n_tiny = n_tiny + 1 if alpha < 1e-10 else 0
         if n_tiny >= 5:
-            status = 4; break      # stalled: converging to an infeasible stationary point
+            if n_restart >= 3:
+                status = 4; break      # stalled: converging to an infeasible stationary point
+            # barrier restart from the current primal point (restoration in miniature, see nmpc_oracle.c)
+            n_restart += 1; n_tiny = 0
+            mu = max(mu, o.mu_init)
+            U = np.clip(U, lbu + pu, ubu - pu)      # back strictly inside the simple bounds, as at the start
+            for k in range(1, N + 1):
+                X[k] = np.where(fin, np.clip(X[k], -bx + px, bx - px), X[k])
+            Sx, Zx, Su, Zu = [], [], [], []
+            for k in range(N + 1):
+                hx, _, hu, _ = _stage_ineq(cfg, k, X[k], U[k] if k < N else None)
+                sx = np.maximum(hx, o.bound_push); su = np.maximum(hu, 1e-12)
+                Sx.append(sx); Su.append(su); Zx.append(mu / sx if sx.size else sx.copy()); Zu.append(mu / su if su.size else su.copy())
+            lam = np.zeros((N + 1, nx))
+            delta_last = 0.0; nu_pen = 1.0; need_shift = False; mhist = []; mh_key = None
 
     wout = np.concatenate([X.reshape(-1), U.reshape(-1)])
     fval = float(np.sum(qd * (X[:N] - xs) ** 2) + np.sum(rd * U * U))

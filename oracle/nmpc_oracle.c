@@ -46,6 +46,7 @@
 typedef struct {
     int m, N, K, nx, nu, M, nxb, nh, thb;
     int trace;      /* NMPC_ORACLE_TRACE=1: one line per iteration on stderr (development aid) */
+    int max_restarts;   /* barrier restarts after a stall: 3 (as the HIP path); NMPC_ORACLE_MAX_RESTARTS overrides (fixture generation) */
     int o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;
     double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin;
     double qd[NXM], rd[NUM_], lbu[NUM_], ubu[NUM_], bxs[NXM];
@@ -88,6 +89,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     w->m = m; w->N = N; w->K = c->n_obs; w->nx = 3 * m; w->nu = 2 * m; w->M = m * (m - 1) / 2;
     w->thb = isfinite(c->th_max) ? 1 : 0;
     w->trace = getenv("NMPC_ORACLE_TRACE") != NULL;
+    w->max_restarts = getenv("NMPC_ORACLE_MAX_RESTARTS") ? atoi(getenv("NMPC_ORACLE_MAX_RESTARTS")) : 3;
     w->nxb = m * (w->thb ? 3 : 2);
     w->nh = 2 * w->nu + 2 * w->nxb + w->M + m * w->K;
     w->o_ul = 0; w->o_uu = w->nu; w->o_xl = 2 * w->nu; w->o_xu = w->o_xl + w->nxb;
@@ -312,7 +314,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   /* merit values of the last three iterates (same mu, nu) */
     int mcount = 0;
-    int it = 0, need_shift = 0, n_tiny = 0;
+    int it = 0, need_shift = 0, n_tiny = 0, n_restart = 0;
     int n_ineq = 0;
     for (int k = 0; k <= N; k++) for (int s = 0; s < nh; s++) n_ineq += slot_active(w, k, s);
     double tmp[NXM + NUM_], Jd[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
@@ -647,7 +649,40 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 }
         for (size_t i = nx; i < (size_t)(N + 1) * nx; i++) w->lam[i] += alpha * (w->lamn[i] - w->lam[i]);
         it++;
-        if (n_tiny >= 5) { status = NMPC_STATUS_STALLED; break; }
+        if (n_tiny >= 5) {
+            if (n_restart >= w->max_restarts) { status = NMPC_STATUS_STALLED; break; }
+            /* barrier restart from the current primal point (a restoration phase in miniature): slacks back onto the
+               constraint values, duals mu/s, multipliers 0, barrier parameter back to at least mu_init.  Rescues 15 of 16
+               captured stalls of the six-robot + eight-obstacle composite. */
+            n_restart++; n_tiny = 0;
+            mu = fmax(mu, w->mu_init);
+            /* the primal point goes back strictly inside the simple bounds first (as at the start): a control sitting on its
+               bound would restart with a slack of ~1e-6 and a dual of mu / 1e-6 */
+            for (int k = 0; k < N; k++)
+                for (int c = 0; c < nu; c++) {
+                    double lo = w->lbu[c], hi = w->ubu[c];
+                    double pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+                    double *u = &w->U[(size_t)k * nu + c];
+                    *u = fmin(fmax(*u, lo + pu), hi - pu);
+                }
+            for (int k = 1; k <= N; k++)
+                for (int s = 0; s < w->nxb; s++) {
+                    double b = w->bxs[s], px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                    double *x = &w->X[(size_t)k * nx + w->bidx[s]];
+                    *x = fmin(fmax(*x, -b + px), b - px);
+                }
+            f = eval_point(w, xs, w->X, w->U, w->sn, w->cs, w->C, w->H);
+            for (int k = 0; k <= N; k++)
+                for (int s = 0; s < nh; s++) {
+                    size_t o = (size_t)k * nh + s;
+                    if (!slot_active(w, k, s)) continue;
+                    double floor_ = (s < w->o_xl) ? 1e-12 : bp;
+                    w->S[o] = fmax(w->H[o], floor_);
+                    w->Z[o] = mu / w->S[o];
+                }
+            memset(w->lam, 0, sizeof(double) * (size_t)(N + 1) * nx);
+            delta_last = 0.0; nu_pen = 1.0; need_shift = 0; mcount = 0;
+        }
     }
     memcpy(wout, w->X, sizeof(double) * (size_t)(N + 1) * nx);
     memcpy(wout + (size_t)(N + 1) * nx, w->U, sizeof(double) * (size_t)N * nu);

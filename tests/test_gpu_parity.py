@@ -305,8 +305,24 @@ def test_stalled_solve_reports_status_4(built):
     ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"][None], d["w"][None])
     r = _np(_solver(ocfg, 1, max_iter=2000).solve_batch(d["p"][None], d["w"][None]))
     assert ref["status"][0] == 4 and r["status"][0] == 4, (ref["status"], r["status"])
-    assert ref["iters"][0] < 200 and abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 5
-    assert abs(r["kkt"][0] - ref["kkt"][0]) <= 1e-3 * ref["kkt"][0]
+    # three barrier restarts (slacks / duals re-initialised from the interior-pushed current point) are tried before giving up
+    assert ref["iters"][0] < 1000 and abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 10
+    assert abs(r["kkt"][0] - ref["kkt"][0]) <= 1e-2 * ref["kkt"][0]
+
+
+def test_barrier_restart_rescues_composite_stalls(built):
+    """tests/golden/restart_cases.npz: warm-started solves of the six-robot + eight-obstacle composite (BASELINE config 5)
+    captured from a closed-loop soak where the solve stalled at an infeasible stationary point; with the barrier restart the
+    HIP path and the oracle converge on the same ones."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "restart_cases.npz"))
+    ocfg = _composite_cfg()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"], d["w"])
+    r = _np(_solver(ocfg, len(d["p"]), max_iter=2000).solve_batch(d["p"], d["w"]))
+    assert (ref["status"] == 0).mean() >= 0.75, ref["status"]
+    assert (r["status"] == ref["status"]).mean() >= 0.75, (r["status"], ref["status"])
+    both = (r["status"] == 0) & (ref["status"] == 0)
+    assert (r["kkt"][both] <= 1e-8).all()
 
 
 def test_random_configurations_match_oracle(built):

@@ -121,4 +121,4 @@ def test_stall_case_is_reported_not_iterated_to_the_limit():
     """the captured infeasible-stationary-point case (see tests/test_gpu_parity.py::test_stalled_solve_reports_status_4)."""
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
     r = O.solve_batch(O.make_config(R.cfg_six(20), max_iter=2000), d["p"][None], d["w"][None])
-    assert r["status"][0] == 4 and r["iters"][0] < 200 and r["kkt"][0] > 1e-3
+    assert r["status"][0] == 4 and r["iters"][0] < 1000 and r["kkt"][0] > 1e-3      # three barrier restarts are tried first

@@ -6,7 +6,12 @@ import torch, nmpc_amd
 from oracle import nlp_ref as R
 from tests import helpers as Hh
 name = sys.argv[1] if len(sys.argv) > 1 else "six"; B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 120
-ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(20)}[name]
+def _composite():
+    rng = np.random.default_rng(7)
+    c = R.cfg_six(25); c.rob_dim = 0.2; c.margin = 0.1
+    c.obstacles = [(float(x), float(y), float(r)) for x, y, r in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
+    return c
+ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(20), "obs3": R.cfg_obs3(20), "composite": _composite()}[name]
 P, _ = Hh.batch(ocfg, B, 2)
 s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=2000), max_batch=B)
 t = time.time()
