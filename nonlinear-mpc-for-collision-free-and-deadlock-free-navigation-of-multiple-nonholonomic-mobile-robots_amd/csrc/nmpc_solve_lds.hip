@@ -409,8 +409,6 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     };
 
     double mu = P.mu_init;
-    trig();
-    __syncthreads();
     // ---- slacks and duals from the current primal point (also the barrier restart after a stall)
     auto init_barrier = [&]() {
         for (int it = tid; it < N1 * NP; it += TPB) {
@@ -446,17 +444,40 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         }
         __syncthreads();
     };
-    init_barrier();
     double f, lgs, th0, e_c, e_h;
-    merit(0.0, f, lgs, th0, e_c, e_h);
-
-    double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
-    bool need_shift = false;
+    double delta_last, nu_pen, kkt = INFINITY;
+    bool need_shift, restarting = false;
     int n_tiny = 0, n_restart = 0;      // consecutive iterations with a step length below 1e-10 (stall -> restart, then NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
-    int mcount = 0;
+    int mcount;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
     const double n_ineq = (double)P.n_ineq;
+
+    // (Re)start of the barrier iteration.  The first pass is the start of the solve; a later pass is the barrier restart after a
+    // stall (restoration in miniature, see the oracle): the primal point goes back strictly inside the simple bounds (a control
+    // sitting on its bound would restart with a slack of ~1e-6 and a dual of mu / 1e-6), slacks return onto the constraint
+    // values, duals = mu / s, multipliers = 0.  One call site for the initialisation keeps the register budget of the main loop.
+    for (;;) {
+    if (restarting) {
+        for (int e = tid + NX; e < N1 * NX; e += TPB) {
+            const int d = (e % NX) % 3;
+            if (d < 2 || THB) {
+                double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                X[e] = fmin(fmax(X[e], -b + px), b - px);
+            }
+            LAM[e] = 0.0;
+        }
+        for (int e = tid; e < N * NU; e += TPB) {
+            double lo = lbu(e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+            U[e] = fmin(fmax(U[e], lo + pu), hi - pu);
+        }
+        __syncthreads();
+    }
+    trig();
+    __syncthreads();
+    init_barrier();
+    merit(0.0, f, lgs, th0, e_c, e_h);
+    delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false;
     PROF_T(0);
 
     for (;;) {
@@ -1138,30 +1159,13 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         PROF_T(8);
         if (n_tiny >= 5) {
             if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
-            // barrier restart from the current primal point (restoration in miniature, see the oracle)
             n_restart++; n_tiny = 0;
             mu = fmax(mu, P.mu_init);
-            // the primal point goes back strictly inside the simple bounds first (a control sitting on its bound would restart
-            // with a slack of ~1e-6 and a dual of mu / 1e-6)
-            for (int e = tid + NX; e < N1 * NX; e += TPB) {
-                const int d = (e % NX) % 3;
-                if (d < 2 || THB) {
-                    double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
-                    X[e] = fmin(fmax(X[e], -b + px), b - px);
-                }
-                LAM[e] = 0.0;
-            }
-            for (int e = tid; e < N * NU; e += TPB) {
-                double lo = lbu(e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
-                U[e] = fmin(fmax(U[e], lo + pu), hi - pu);
-            }
-            __syncthreads();
-            trig();
-            __syncthreads();
-            init_barrier();
-            merit(0.0, f, lgs, th0, e_c, e_h);
-            delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0;
+            restarting = true;
+            break;
         }
+    }
+    if (!restarting) break;
     }
 
     __syncthreads();
