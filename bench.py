@@ -33,6 +33,14 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak
 HBM_PEAK_GBS = 8000.0
 
 
+def _composite(R):
+    """six robots (C6 literals) + 8 circular obstacles in [-1.5, 1.5]^2, radii U[0.125, 0.2], rob_dim 0.2, margin 0.1, N = 25."""
+    rng = np.random.default_rng(7)
+    c = R.cfg_six(25); c.rob_dim = 0.2; c.margin = 0.1
+    c.obstacles = [(float(x), float(y), float(r)) for x, y, r in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
+    return c
+
+
 def workload(name: str):
     """(oracle NLPConfig, batch per GPU, config index) — literals from the reference scripts."""
     from oracle import nlp_ref as R
@@ -40,6 +48,7 @@ def workload(name: str):
         "two": (R.cfg_two(20), 1024, 1),
         "six": (R.cfg_six(20), 4096, 2),
         "ten": (R.cfg_ten(30), 512, 3),
+        "composite": (_composite(R), 1024, 4),      # BASELINE.json configs[4]: synthetic, no reference script (mismatch 2)
     }
     return table[name]
 
@@ -62,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="six", choices=["two", "six", "ten"])
+    ap.add_argument("--workload", default="six", choices=["two", "six", "ten", "composite"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--max-iter", type=int, default=2000)
     ap.add_argument("--closed-loop", type=int, default=20, help="warm closed-loop steps reported as an extra (0 = skip)")
@@ -147,8 +156,8 @@ def main():
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, batch=%d per GPU, cold start" %
-                   (args.workload, ocfg.m, ocfg.N, ocfg.M, B), "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol},
+        "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d per GPU, cold start" %
+                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol},
         "solve_stats": {"mean_iters": sum_iters / (B * world), "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / (B * world), "max_kkt_converged": float(allst[:, 4].max())},
         "roofline": {"bound": "mfma", "kernel": "nmpc::solve_lds_kernel<%d,...>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
