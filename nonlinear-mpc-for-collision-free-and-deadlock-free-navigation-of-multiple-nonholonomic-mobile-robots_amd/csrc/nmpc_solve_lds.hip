@@ -1,23 +1,24 @@
-// nmpc_solve_lds.hip — latency-oriented gfx950 solve kernel ("v2").
+// nmpc_solve_lds.hip — latency-oriented gfx950 solve kernel (the hot kernel).
 //
-// The batch's wall time is set by the slowest instance (every instance is resident at once and
-// iteration counts have a long tail), so this kernel minimises the latency of ONE interior-point
-// iteration of ONE instance:
-//   * one wavefront (64 lanes) per swarm instance — every "barrier" is a wave-local LDS fence;
-//   * the whole iterate (X, U, lambda, step, all slacks and duals, sin/cos cache) lives in LDS for the
-//     entire solve;
-//   * everything of a stage that does not depend on the cost-to-go (gradients, barrier Hessian
-//     terms, the 3x2 Jacobian entries T cos, T sin, -T v sin, T v cos per robot) is computed for all
-//     stages in parallel ("stage packs", written to HBM/L2 and prefetched one stage ahead);
+// A launch takes as long as "start of the longest instance + its length", so this kernel minimises the latency of ONE
+// interior-point iteration of ONE instance:
+//   * one wavefront (64 lanes) per swarm instance up to six robots (2 / 4 waves for 8 / 10 robots, and for small batches) —
+//     every "barrier" of a single-wave instance is a wave-local LDS fence;
+//   * the iterate (X, U, lambda, pair / obstacle slacks and duals, control-bound slacks and duals, state-bound duals, sin/cos
+//     cache) lives in LDS for the entire solve; the step and the adjoint residuals overlay the Riccati working set;
+//   * everything of a stage that does not depend on the cost-to-go (gradients, barrier Hessian terms, the 3x2 Jacobian entries
+//     T cos, T sin, -T v sin, T v cos per robot) is computed for all stages in parallel ("stage packs", written to HBM/L2 and
+//     prefetched one stage ahead);
 //   * one Riccati stage = assemble the augmented symmetric matrix
 //         [ Quu Qux | qu ]      = [B A]^T P [B A] + H     (upper triangle + rhs column)
 //         [ Qxu Qxx | qx ]
-//     directly from P with the robot-sparse A,B (<= 3 terms per index), held in REGISTERS, one
-//     static set of elements per lane; NU pivot steps of symmetric elimination publish one pivot row
-//     per step through LDS; what remains in the registers is [P_k | p_k].  The feedback gains come
-//     from an in-register back substitution (one lane per column) and stream to HBM transposed;
-//   * forward sweep: gains prefetched a stage ahead, one LDS turnaround per stage;
-//   * multipliers: stage-parallel residual pass + robot-local adjoint recursion in registers.
+//     directly from P with the robot-sparse A, B (<= 3 terms per index), held in REGISTERS, one static set of elements per
+//     lane (per-lane offset tables rebuilt at the start of every sweep); NU pivot steps of symmetric elimination publish one
+//     pivot row per step through LDS; what remains in the registers is [P_k | p_k].  No feedback gains are formed: the pivot
+//     rows and reciprocal pivots stream to HBM/L2 and the forward sweep does one triangular solve per stage with v_readlane;
+//   * every wave reduction ends in v_readfirstlane (uniform_f64): the control decisions of the solve are scalar branches;
+//   * multipliers: stage-parallel residual pass + robot-local adjoint recursion in registers;
+//   * a stall (5 steps below 1e-10) restarts the barrier iteration from the interior-pushed current point, at most 3 times.
 //
 // Reference blocks replaced: see nmpc_kernels.hip (same algorithm, same constants as the oracle).
 #include <hip/hip_runtime.h>

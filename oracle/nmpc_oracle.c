@@ -24,7 +24,13 @@
  *           diagonal only (every Quu_k > 0 is what the Riccati sweep needs), bound_push=1e-2; the linear system
  *           is solved by a Riccati sweep over the stages (block elimination of the same
  *           KKT matrix) and the line search is a non-monotone l1-merit backtracking search
- *           (reference = max of the last four merit values) instead of IPOPT's filter.  Parity is therefore at the KKT point, not on iterates.
+ *           (reference = max of the last four merit values) instead of IPOPT's filter.
+ *           Further deliberate differences (each measured): mu_init = 0.5, the
+ *           dual step is capped by the accepted primal step, the first inertia trial after
+ *           an iteration that needed a shift is a quarter of that shift, and a stall (5
+ *           steps below 1e-10) triggers a barrier restart from the interior-pushed current
+ *           point (at most 3, then NMPC_STATUS_STALLED) in place of IPOPT's restoration
+ *           phase.  Parity is therefore at the KKT point, not on iterates.
  *   shift:  C6:160-169,460-465; plant step AllScripts/casadi_test.py:17-26.
  *
  * Plain scalar C99, one instance at a time; the batch driver runs instances in
