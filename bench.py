@@ -201,9 +201,11 @@ def main():
         nx = cfg.nx
         Pc, Wc = dP.clone(), dW0.clone()
         its, conv = [], []
+        prev_it = None      # dispatch-order hint of nmpc_solve_batch_ordered: previous period's iteration counts, longest first
         torch.cuda.synchronize(); t2 = time.perf_counter()
         for _ in range(args.closed_loop):
-            rr = solver.solve_batch(Pc, Wc)
+            rr = solver.solve_batch(Pc, Wc, order=None if prev_it is None else torch.argsort(prev_it, descending=True))
+            prev_it = rr["iters"]
             Wc, x0n = solver.shift_batch(Pc, rr["x"], plant=True)
             Pc = torch.cat([x0n, Pc[:, nx:]], dim=1)
             its.append(rr["iters"]); conv.append(rr["status"])
@@ -213,7 +215,7 @@ def main():
                               "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
                               "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
                               "converged_frac": float((conv == 0).mean()),
-                              "note": "warm-started receding horizon: solve, then nmpc_shift_batch (plant step x0+T f(x0,u0) and guess shift) on device"}
+                              "note": "warm-started receding horizon: solve (dispatch order = previous period's iteration counts, longest first), then nmpc_shift_batch (plant step x0+T f(x0,u0) and guess shift) on device"}
         torch.cuda.synchronize(); t3 = time.perf_counter()
         rh = solver.solve_batch(P, W0)
         xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()

@@ -105,6 +105,16 @@ int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const dou
                          double *obj, int32_t *status, int32_t *iters, double *kkt, void *stream);
 
 /*
+ * nmpc_solve_batch with a dispatch-order hint: order [B] (device, int32) is a permutation of 0..B-1 and workgroup g solves
+ * instance order[g]; results land at the instance's own index, exactly as without the hint.  The launch takes as long as
+ * "start of the longest solve + its length", so a caller that can rank the instances by expected effort (in a receding-horizon
+ * loop: by the iteration counts of the previous control period, rank correlation 0.6-0.7) puts the long ones first.
+ * order == NULL is nmpc_solve_batch.  No reference counterpart (the reference solves one instance per call, C6:432).
+ */
+int32_t nmpc_solve_batch_ordered(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
+                                 int32_t *status, int32_t *iters, double *kkt, const int32_t *order, void *stream);
+
+/*
  * Evaluates the NLP functions in the reference's layout at w: f (C6:314) and
  * g [B][n_g] (C6:278,318-331).  Backs sol['f'] / sol['g'] of the host wrapper.
  */

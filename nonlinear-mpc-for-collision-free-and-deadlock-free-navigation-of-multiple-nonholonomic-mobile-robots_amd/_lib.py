@@ -16,7 +16,7 @@ STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Erro
 ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMPC_E_NOMEM"}
 
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_destroy",
-           "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
+           "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
 
 
 class CConfig(C.Structure):
@@ -55,6 +55,7 @@ def load():
     L.nmpc_destroy.argtypes = [vp]; L.nmpc_destroy.restype = i32
     L.nmpc_workspace_bytes.argtypes = [vp]; L.nmpc_workspace_bytes.restype = C.c_int64
     L.nmpc_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch.restype = i32
+    L.nmpc_solve_batch_ordered.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch_ordered.restype = i32
     L.nmpc_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_eval_batch.restype = i32
     L.nmpc_shift_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_shift_batch.restype = i32
     L.nmpc_odometry_batch.argtypes = [C.c_int64, vp, vp, vp, vp]; L.nmpc_odometry_batch.restype = i32

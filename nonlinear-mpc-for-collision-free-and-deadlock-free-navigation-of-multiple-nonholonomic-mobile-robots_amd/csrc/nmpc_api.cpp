@@ -114,16 +114,30 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
 
 int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 0; }
 
-int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
-                         int32_t *iters, double *kkt, void *stream)
+static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                          int32_t *iters, double *kkt, const int32_t *order, void *stream)
 {
     if (!h || B < 0 || B > h->max_batch) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;      /* empty batch: nothing to read or write, pointers may be null */
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
+    nmpc::KParams P = h->P;
+    P.order = order;
     hipError_t e = (h->kernel == 1)
-                       ? nmpc::launch_solve(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
-                       : nmpc::launch_solve_lds(h->P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
+                       ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
+                       : nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                         int32_t *iters, double *kkt, void *stream)
+{
+    return solve_impl(h, B, p, w0, w_out, obj, status, iters, kkt, nullptr, stream);
+}
+
+int32_t nmpc_solve_batch_ordered(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
+                                 int32_t *status, int32_t *iters, double *kkt, const int32_t *order, void *stream)
+{
+    return solve_impl(h, B, p, w0, w_out, obj, status, iters, kkt, order, stream);
 }
 
 int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream)

@@ -17,6 +17,7 @@ struct KParams {
     // per-instance workspace carve-up, in doubles
     int64_t stride;
     int32_t trace_inst, pad_;   // NMPC_PROFILE builds: instance whose per-iteration trace is recorded
+    const int32_t *order;       // per call: dispatch order (workgroup g solves instance order[g]) or nullptr = identity
     int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
     int64_t oPACK, oKT;
     int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;

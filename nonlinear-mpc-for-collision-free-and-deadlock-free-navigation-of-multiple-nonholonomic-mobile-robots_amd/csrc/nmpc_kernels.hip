@@ -167,7 +167,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     const int tid = threadIdx.x;
     const int N = P.N, NH = P.nh;
     const double T = P.T;
-    const size_t inst = blockIdx.x;
+    const size_t inst = P.order ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;
 
     __shared__ double sP[NX * NX];   // P_{k+1}, then Qxx, then P_k
     __shared__ double sG[NX * NZ];   // P [A B]

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     const int tid = threadIdx.x;
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
-    const size_t inst = blockIdx.x;
+    const size_t inst = P.order ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;      // dispatch-order hint: long solves first
 
     extern __shared__ double sm[];
     double *X = sm;                       // [N1*NX]

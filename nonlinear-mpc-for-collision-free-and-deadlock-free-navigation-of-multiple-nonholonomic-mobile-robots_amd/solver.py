@@ -118,8 +118,11 @@ class NmpcSolver:
         return t
 
     # ---- batched device API -----------------------------------------------------------------
-    def solve_batch(self, p, w0, want_fg: bool = False):
-        """p [B, 2 n_x], w0 [B, n_var] (torch cuda / numpy) -> dict of torch cuda tensors."""
+    def solve_batch(self, p, w0, want_fg: bool = False, order=None):
+        """p [B, 2 n_x], w0 [B, n_var] (torch cuda / numpy) -> dict of torch cuda tensors.
+
+        order: optional permutation of range(B) (dispatch-order hint, nmpc_solve_batch_ordered): workgroup g solves instance
+        order[g]; put the instances expected to need the most iterations first.  Results are unaffected."""
         torch = self.torch
         p = self._dev(p, (-1, self.n_p)); B = p.shape[0]
         w0 = self._dev(w0, (B, self.n_var))
@@ -131,8 +134,15 @@ class NmpcSolver:
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = torch.empty(B, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.nmpc_solve_batch(self._h, B, p.data_ptr(), w0.data_ptr(), w.data_ptr(), obj.data_ptr(),
-                                                 status.data_ptr(), iters.data_ptr(), kkt.data_ptr(), self._stream()), "nmpc_solve_batch")
+            if order is None:
+                _lib.check(self.lib.nmpc_solve_batch(self._h, B, p.data_ptr(), w0.data_ptr(), w.data_ptr(), obj.data_ptr(),
+                                                     status.data_ptr(), iters.data_ptr(), kkt.data_ptr(), self._stream()), "nmpc_solve_batch")
+            else:
+                od = torch.as_tensor(order, device=self.device).to(torch.int32).contiguous()
+                if od.shape != (B,):
+                    raise ValueError(f"order must have shape ({B},)")
+                _lib.check(self.lib.nmpc_solve_batch_ordered(self._h, B, p.data_ptr(), w0.data_ptr(), w.data_ptr(), obj.data_ptr(), status.data_ptr(),
+                                                             iters.data_ptr(), kkt.data_ptr(), od.data_ptr(), self._stream()), "nmpc_solve_batch_ordered")
         out = dict(x=w, f=obj, status=status, iters=iters, kkt=kkt)
         if want_fg:
             f, g = self.eval_batch(p, w)

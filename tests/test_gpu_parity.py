@@ -355,3 +355,20 @@ def test_random_configurations_match_oracle(built):
         rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
         assert (rel[same] <= F_RTOL).all(), (tag, rel)
         assert (r["kkt"][r["status"] == 0] <= 1e-8).all(), tag
+
+
+def test_dispatch_order_hint_does_not_change_results(built):
+    """nmpc_solve_batch_ordered: any permutation as dispatch order gives bit-identical results at the instances' own indices."""
+    import torch
+    ocfg = R.cfg_six(20)
+    B = 96
+    P, W0 = Hh.batch(ocfg, B, 2)
+    s = _solver(ocfg, B)
+    r0 = _np(s.solve_batch(P, W0))
+    rng = np.random.default_rng(5)
+    for order in (np.arange(B)[::-1].copy(), rng.permutation(B), np.argsort(-r0["iters"], kind="stable")):
+        r1 = _np(s.solve_batch(P, W0, order=order)); torch.cuda.synchronize()
+        for k in ("x", "f", "status", "iters", "kkt"):
+            assert np.array_equal(r0[k], r1[k]), k
+    with pytest.raises(ValueError):
+        s.solve_batch(P, W0, order=np.arange(B - 1))
