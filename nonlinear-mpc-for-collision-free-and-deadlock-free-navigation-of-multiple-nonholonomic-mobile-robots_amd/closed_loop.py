@@ -38,7 +38,7 @@ class EpisodeResult:
 
 def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol: float = 5e-2, coll_tol: float = 1e-6,
                          window: int = 10, move_tol: float = 1e-3, keep_states: bool = False,
-                         on_failure: str = "apply") -> EpisodeResult:
+                         on_failure: str = "apply", order_hint: bool = True) -> EpisodeResult:
     """Run B closed-loop episodes.  x0: [B, n_x]; goals: [B, n_x] or [B, G, n_x] (visited in order).
 
     on_failure: what a swarm does in a period whose solve did not converge (status != 0; ~1 in 1e5 warm solves stall at an
@@ -101,7 +101,7 @@ def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol
         p = torch.cat([x, xs], dim=1)
         # dispatch-order hint: the swarms that needed the most iterations in the previous period go first (rank correlation of
         # consecutive periods' iteration counts 0.6-0.7; -12 % launch time on the six-robot batch)
-        r = solver.solve_batch(p, w, order=None if prev_iters is None else torch.argsort(prev_iters, descending=True))
+        r = solver.solve_batch(p, w, order=None if (prev_iters is None or not order_hint) else torch.argsort(prev_iters, descending=True))
         prev_iters = r["iters"]
         total += B
         failed += int((r["status"] != 0).sum())

@@ -15,7 +15,7 @@ ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(20), "obs3"
 P, _ = Hh.batch(ocfg, B, 2)
 s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=2000), max_batch=B)
 t = time.time()
-ep = nmpc_amd.simulate_closed_loop(s, P[:, : ocfg.nx], P[:, ocfg.nx:], max_steps=steps, stop_tol=0.3, on_failure=os.environ.get("ON_FAILURE", "apply"))
+ep = nmpc_amd.simulate_closed_loop(s, P[:, : ocfg.nx], P[:, ocfg.nx:], max_steps=steps, stop_tol=0.3, on_failure=os.environ.get("ON_FAILURE", "apply"), order_hint=os.environ.get("ORDER_HINT", "1") == "1")
 dt = time.time() - t
 print(f"{name} B={B} steps={ep.steps}: {ep.total_solves / dt:.0f} solves/s, failed solves {ep.failed_solves}/{ep.total_solves}, "
       f"arrived {ep.arrived.mean():.3f}, collision-free {ep.collision_free.mean():.4f}, deadlocked {ep.deadlocked.mean():.3f}, "
