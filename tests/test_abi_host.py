@@ -139,3 +139,20 @@ def test_independent_robot_mode_packing(built):
     for b in range(B):
         f_sum = sum(R.objective(c1, w1[b * m + i], p1[b * m + i]) for i in range(m))
         assert abs(R.objective(cm, w[b], p[b]) - f_sum) <= 1e-12 * max(1.0, abs(f_sum))
+
+
+def test_bench_roofline_inputs_match_survey():
+    """algorithmic bytes / flops per solve that bench.py prices the roofline with."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    want = {"one": (R.cfg_one(20), 1712, 3.23e3), "two": (R.cfg_two(20), 3408, 25.9e3), "six": (R.cfg_six(20), 10192, 698.4e3),
+            "ten30": (R.cfg_ten(30), 24976, 4.85e6), "ten20": (R.cfg_ten(20), 16976, 3.23e6)}
+    for name, (cfg, nbytes, fkkt) in want.items():
+        assert bench.algorithmic_bytes_per_solve(cfg) == nbytes, name
+        f_asm = cfg.N * (22.0 * cfg.m + 14.0 * cfg.M + 16.0 * cfg.m * cfg.K)
+        assert abs(bench.algorithmic_flops_per_iter(cfg) - f_asm - fkkt) <= 0.005 * fkkt, (name, bench.algorithmic_flops_per_iter(cfg) - f_asm)
+    # every workload of the bench resolves to a configuration and a batch size
+    for wname, (m, N, B) in {"two": (2, 20, 1024), "six": (6, 20, 4096), "ten": (10, 30, 512), "composite": (6, 25, 1024)}.items():
+        cfg, b, _ = bench.workload(wname)
+        assert (cfg.m, cfg.N, b) == (m, N, B)
