@@ -90,9 +90,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # NMPC_BENCH_REHEARSAL=1: every rank on device 0 with the gloo backend — rehearses the N > 1 code path on a one-GPU box
+    rehearsal = bool(os.environ.get("NMPC_BENCH_REHEARSAL"))
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ocfg, B, cidx = workload(args.workload)
     if args.batch:
@@ -134,6 +139,8 @@ def main():
     stats = torch.tensor([dt, float(iters.sum()), float((status == 0).sum()), float(iters.max()), float(kkt[status == 0].max() if (status == 0).any() else 0.0), kern_ms],
                          dtype=torch.float64, device="cuda")
     if world > 1:
+        if rehearsal:
+            stats = stats.cpu()
         allst = [torch.empty_like(stats) for _ in range(world)]
         dist.all_gather(allst, stats)
         allst = torch.stack(allst).cpu().numpy()
