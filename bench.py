@@ -2,25 +2,32 @@
 """bench.py — NMPC solves/sec (batched swarms) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one nmpc_solve_batch over one batch of synthetic swarm instances (cold start,
-inputs already resident in HBM, result write-back to HBM included).  Workload at every N:
-BASELINE.json configs[2] — 6 robots, horizon N=20, 15 pair rows per stage, batch 4096 per GPU
-(weak scaling: instances are independent, each rank solves its own 4096; no data-path collective,
-one all_gather of the per-rank timings/counters at the end).
+With N > 1 and no launcher environment (WORLD_SIZE unset) this process starts N ranks itself, as a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`, before it
+has made any GPU call, and exits with the child's code; under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank.
 
-Prints ONE JSON line on rank 0 (see README of the task for the contract) including
-  roofline     — the solve kernel against the fp64 matrix/vector peak, algorithmic flops of
-                 SURVEY.md §8(d): iters * (F_kkt + F_asm) per solve, duration from HIP events;
-  cpu_baseline — the C oracle (oracle/nmpc_oracle.c, OpenMP, one instance per thread) timed on
-                 this box's host cores on a bounded sample of the same workload ("port").
+A "step" is one nmpc_solve_batch over one batch of synthetic swarm instances (cold start, inputs already resident in HBM,
+result write-back to HBM included).  Workload at every N: BASELINE.json configs[2] — 6 robots, horizon N=20, 15 pair rows per
+stage, batch 4096 per GPU (weak scaling: instances are independent, each rank solves its own 4096; no data-path collective).
+The one collective the path has, the result gather (RCCL all_gather of w_out / status / iters), is timed
+separately after the solve steps and reported under "gather".
+
+Prints ONE JSON line on rank 0 including
+  roofline     — the solve kernel against the fp64 vector peak (the kernel issues no MFMA), algorithmic flops of
+                 SURVEY.md §8(d): iters * (F_kkt + F_asm) per solve, duration from HIP events on the launch stream;
+  cpu_baseline — the C oracle (oracle/nmpc_oracle.c, OpenMP, one instance per thread) timed on this box's host cores on a
+                 bounded sample of the same workload ("port");
+  sweep        — (N = 1 only) the other north-star shapes, each with its own roofline: m=2 and m=10 at N=20, B=4096; m=10 at
+                 N=30, B=512; the six-robot + eight-obstacle composite.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -45,9 +52,10 @@ def workload(name: str):
     """(oracle NLPConfig, batch per GPU, config index) — literals from the reference scripts."""
     from oracle import nlp_ref as R
     table = {
-        "two": (R.cfg_two(20), 1024, 1),
-        "six": (R.cfg_six(20), 4096, 2),
-        "ten": (R.cfg_ten(30), 512, 3),
+        "two": (R.cfg_two(20), 4096, 1),            # north_star: N_robots=2, N=20, batch 4096 (BASELINE configs[1] quotes 1024)
+        "six": (R.cfg_six(20), 4096, 2),            # BASELINE configs[2], the headline
+        "ten20": (R.cfg_ten(20), 4096, 3),          # north_star: N_robots=10, N=20, batch 4096 (the file's own horizon)
+        "ten": (R.cfg_ten(30), 512, 3),             # BASELINE configs[3]: N=30, 512 per GPU
         "composite": (_composite(R), 1024, 4),      # BASELINE.json configs[4]: synthetic, no reference script (SURVEY.md 0, mismatch 2)
     }
     return table[name]
@@ -66,17 +74,104 @@ def algorithmic_bytes_per_solve(cfg) -> float:
     return 8.0 * (2 * cfg.nx + 2 * cfg.n_var) + 16.0 + 8.0 * 3 * cfg.K
 
 
+def _free_port() -> int:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a child torch.distributed.run (this process has not touched the GPU and
+    never will; it only relays the child's output and exit code)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def make_batch(name, rank, batch=0):
+    import nmpc_amd
+    from tests import helpers as Hh
+    from oracle import nlp_ref as R
+    ocfg, B, cidx = workload(name)
+    if batch:
+        B = batch
+    # synthetic instances of SURVEY.md §8(d); each rank draws its own shard (seed + rank stream)
+    rng = np.random.Generator(np.random.PCG64([Hh.SEED0 + cidx, rank]))
+    P = np.stack([Hh.instance(rng, ocfg) for _ in range(B)])
+    # SURVEY.md 8(d): instance 0 of every batch is the reference's literal start/goal set (C6:364-388, C2:213-224); the literal
+    # x0 of the ten-robot script has coincident robots (status 3 by construction), so that workload keeps its drawn instance
+    lit = {"six": (R.C6_START, R.C6_GOAL), "two": (R.C2_START, R.C2_GOAL)}.get(name)
+    if lit is not None:
+        P[0] = np.concatenate(lit)
+    W0 = np.stack([R.cold_start(ocfg, p[: ocfg.nx]) for p in P])
+    return ocfg, B, P, W0
+
+
+def timed_solves(solver, dP, dW0, steps, warmup, barrier):
+    """W untimed + K timed nmpc_solve_batch launches; returns (wall seconds between the barriers, mean kernel ms from HIP
+    events recorded on the launch stream, result of the last step)."""
+    import torch
+    r = None
+    for _ in range(warmup):
+        r = solver.solve_batch(dP, dW0)
+    barrier()
+    st = torch.cuda.current_stream()      # the stream nmpc_solve_batch launches on (NmpcSolver._stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record(st)
+        r = solver.solve_batch(dP, dW0)
+        ev[k][1].record(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
+
+
+def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version):
+    fl_iter = algorithmic_flops_per_iter(ocfg)
+    flops_launch = float(sum_iters) * fl_iter
+    achieved = flops_launch / (kern_ms * 1e-3) / 1e12
+    rl = {"bound": "fp64-valu", "kernel": "nmpc::solve_lds_kernel<%d,...>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
+          "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
+          "hbm_frac_of_algorithmic_bytes": algorithmic_bytes_per_solve(ocfg) * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "note": "compute/latency-bound fp64 kernel with zero MFMA instructions: priced against the fp64 VECTOR peak 78.6 TFLOP/s "
+                  "(= the fp64 matrix peak on MI355X); algorithmic flops = iters*(F_kkt+F_asm) of SURVEY.md 8(d)"}
+    # HBM traffic of the solve kernel: FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 --pmc passes (profiles/current, collected
+    # with tools/collect_profiles.sh on the default command, corrected as MI355X_MICROARCH.md prescribes), stored per interior-point
+    # iteration and scaled by the iterations of THIS launch.  The profile is stamped with the source hash of the library it was
+    # taken from: null unless this run's library is that very build and the workload matches.
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "current", "hbm_traffic.json")))
+        same_lib = tj.get("library_src_hash") and ("src=" + tj["library_src_hash"]) in lib_version
+        if same_lib and tj["workload"].get("m") == ocfg.m and tj["workload"].get("N") == ocfg.N and tj["workload"].get("batch_per_gpu") == B:
+            rl["traffic"] = tj["hbm_bytes_per_iteration"] * float(sum_iters)
+            rl["traffic_source"] = "profiles/current/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch" % tj["library_src_hash"]
+            rl["traffic_GBps"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9
+        else:
+            rl["traffic_source"] = "null: profiles/current/hbm_traffic.json was taken from another build or workload (src=%s)" % tj.get("library_src_hash")
+    except (OSError, KeyError, ValueError):
+        pass
+    return rl
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="six", choices=["two", "six", "ten", "composite"])
+    ap.add_argument("--workload", default="six", choices=["two", "six", "ten", "ten20", "composite"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's)")
     ap.add_argument("--max-iter", type=int, default=2000)
     ap.add_argument("--closed-loop", type=int, default=20, help="warm closed-loop steps reported as an extra (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances for the CPU baseline (0 = skip)")
+    ap.add_argument("--sweep", type=int, default=-1, help="north-star sweep entries (default: on for --gpus 1, 0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))        # before any GPU call
 
     import torch
     import torch.distributed as dist
@@ -86,35 +181,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve has no CPU fallback")
     # NMPC_BENCH_REHEARSAL=1: every rank on device 0 with the gloo backend — rehearses the N > 1 code path on a one-GPU box
     rehearsal = bool(os.environ.get("NMPC_BENCH_REHEARSAL"))
+    if not rehearsal and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} devices are visible")
     torch.cuda.set_device(0 if rehearsal else local_rank)
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    ocfg, B, cidx = workload(args.workload)
-    if args.batch:
-        B = args.batch
-    cfg = Hh.to_product_cfg(ocfg, max_iter=args.max_iter)
-    # synthetic instances of SURVEY.md §8(d); each rank draws its own shard (seed + rank stream)
-    rng = np.random.Generator(np.random.PCG64([Hh.SEED0 + cidx, rank]))
-    P = np.stack([Hh.instance(rng, ocfg) for _ in range(B)])
-    # instance 0 of every batch is the reference's literal start/goal set (C6:364-388, C2:213-224); the literal
-    # x0 of the ten-robot script has coincident robots (status 3 by construction), so that workload keeps its drawn instance
-    from oracle import nlp_ref as R
-    lit = {"six": (R.C6_START, R.C6_GOAL), "two": (R.C2_START, R.C2_GOAL)}.get(args.workload)
-    if lit is not None:
-        P[0] = np.concatenate(lit)
-    W0 = np.stack([nmpc_amd.cold_start(cfg, p[: cfg.nx]) for p in P])
-    solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
-    dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {args.gpus}")
+    lib_version = nmpc_amd._lib.load().nmpc_version().decode()
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,21 +205,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        r = solver.solve_batch(dP, dW0)
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        r = solver.solve_batch(dP, dW0)
-        ev[k][1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ocfg, B, P, W0 = make_batch(args.workload, rank, args.batch)
+    cfg = Hh.to_product_cfg(ocfg, max_iter=args.max_iter)
+    solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
+    dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
+    dt, kern_ms, r = timed_solves(solver, dP, dW0, args.steps, args.warmup, barrier)
 
     iters = r["iters"].cpu().numpy(); status = r["status"].cpu().numpy(); kkt = r["kkt"].cpu().numpy()
-    stats = torch.tensor([dt, float(iters.sum()), float((status == 0).sum()), float(iters.max()), float(kkt[status == 0].max() if (status == 0).any() else 0.0), kern_ms],
+    # ---- the result gather of SURVEY.md 8(e): all_gather of w_out / status / iters of every rank's shard, timed on its own
+    gather_ms = 0.0
+    if world > 1:
+        Bg = B * world
+        torch.cuda.synchronize()
+        for rep in range(4):          # first repetition warms the communicator up
+            barrier()
+            tg = time.perf_counter()
+            gw = nmpc_amd.gather_results(r["x"] if not rehearsal else r["x"].cpu(), Bg)
+            gs = nmpc_amd.gather_results((r["status"] if not rehearsal else r["status"].cpu())[:, None], Bg)
+            gi = nmpc_amd.gather_results((r["iters"] if not rehearsal else r["iters"].cpu())[:, None], Bg)
+            torch.cuda.synchronize()
+            if rep:
+                gather_ms += (time.perf_counter() - tg) * 1e3 / 3.0
+        assert gw.shape == (Bg, cfg.n_var) and gs.shape == (Bg, 1) and gi.shape == (Bg, 1)
+        lo = rank * B
+        assert torch.equal(gw[lo: lo + B].to(r["x"].device), r["x"]), "gathered shard differs from the local result"
+    stats = torch.tensor([dt, float(iters.sum()), float((status == 0).sum()), float(iters.max()), float(kkt[status == 0].max() if (status == 0).any() else 0.0), kern_ms, gather_ms],
                          dtype=torch.float64, device="cuda")
     if world > 1:
         if rehearsal:
@@ -154,36 +247,25 @@ def main():
     total_solves = float(B) * world * args.steps
     value = total_solves / t_max
     sum_iters = float(allst[:, 1].sum())
-    fl_iter = algorithmic_flops_per_iter(ocfg)
-    # roofline of the dominant kernel (solve_kernel), per launch on rank 0
-    flops_launch = float(allst[0, 1]) * fl_iter
-    achieved = flops_launch / (allst[0, 5] * 1e-3) / 1e12
     out = {
         "metric": "NMPC solves/sec (batched swarms), N_robots=%d, N=%d" % (ocfg.m, ocfg.N),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d per GPU, cold start" %
-                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol},
+                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "m": ocfg.m, "N": ocfg.N, "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol,
+                   "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
+        "library": lib_version,
         "solve_stats": {"mean_iters": sum_iters / (B * world), "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / (B * world), "max_kkt_converged": float(allst[:, 4].max())},
-        "roofline": {"bound": "mfma", "kernel": "nmpc::solve_lds_kernel<%d,...>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                     "flops_per_launch": flops_launch, "kernel_ms": float(allst[0, 5]),
-                     "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
-                     "note": "fp64 MFMA/VALU peak 78.6 TFLOP/s; algorithmic flops = iters*(F_kkt+F_asm) of SURVEY.md 8(d)"},
+        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version),
     }
-    # HBM traffic of the solve kernel: FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 --pmc passes (profiles/current,
-    # collected with tools/collect_profiles.sh on this same command, corrected as MI355X_MICROARCH.md prescribes), stored per
-    # interior-point iteration and scaled by the iterations of THIS launch; null when no pass exists for this workload
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "current", "hbm_traffic.json")))
-        if tj["workload"]["workload"] == out["config"]["workload"]:
-            out["roofline"]["traffic"] = tj["hbm_bytes_per_iteration"] * float(allst[0, 1])
-            out["roofline"]["traffic_note"] = "bytes/launch = PMC bytes per iteration (profiles/current/hbm_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch"
-            out["roofline"]["traffic_GBps"] = out["roofline"]["traffic"] / (allst[0, 5] * 1e-3) / 1e9
-    except (OSError, KeyError, ValueError):
-        pass
+    if world > 1:
+        per_rank_bytes = B * (cfg.n_var * 8 + 8)
+        gms = float(allst[:, 6].max())
+        out["gather"] = {"collective": "all_gather of w_out [B, n_var] f64 + status + iters (nmpc_amd.gather_results)", "backend": dist.get_backend(),
+                         "ms": gms, "bytes_per_rank_shard": per_rank_bytes, "recv_GBps_per_rank": per_rank_bytes * (world - 1) / (gms * 1e-3) / 1e9 if gms > 0 else None,
+                         "note": "timed separately from the solve steps (mean of 3 after a warm-up); not part of `value`, which is the device-resident solve"}
     # warm closed loop of SURVEY.md 8(d): 20 receding-horizon steps, each = solve + device shift/plant step (a13 + a11);
     # and the same cold solve with HOST buffers at the boundary (H2D of p, w0 and D2H of w included).  Both are extras:
     # `value` above is the device-resident cold solve.
@@ -212,6 +294,24 @@ def main():
         t_h = time.perf_counter() - t3
         out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
                                "note": "same cold batch with pageable host numpy buffers at the boundary: H2D of p and w0, solve, D2H of w/status"}
+    # north-star sweep: N_robots in {2, 6, 10}, N=20, batch 4096 (+ BASELINE configs[3] and [4]); one warm-up + two timed launches each
+    do_sweep = args.sweep if args.sweep >= 0 else (1 if (world == 1 and args.workload == "six" and not args.batch) else 0)
+    if world == 1 and do_sweep:
+        del solver
+        out["sweep"] = []
+        for name in ("two", "ten20", "ten", "composite"):
+            oc2, B2, P2, W2 = make_batch(name, 0)
+            c2 = Hh.to_product_cfg(oc2, max_iter=args.max_iter)
+            s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
+            d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)
+            it2 = r2["iters"].cpu().numpy(); st2 = r2["status"].cpu().numpy()
+            out["sweep"].append({"workload": "%s: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d, cold start" % (name, oc2.m, oc2.N, oc2.M, oc2.K, B2),
+                                 "m": oc2.m, "N": oc2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
+                                 "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
+                                 "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
+                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version)})
+            del s2
+            torch.cuda.empty_cache()
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)
     # CPU baseline: the C oracle on this box's host cores, bounded sample of the same workload
     if world == 1 and args.cpu_sample != 0:

@@ -17,6 +17,13 @@
  * default stream).  Return value: 0 on success, negative NMPC_E_* on argument / HIP
  * errors.  Non-convergence is NOT an error (the reference never reads solver.stats());
  * it is reported per instance in `status`.
+ *
+ * Concurrency: a handle owns ONE device workspace that every solve on it uses, so one
+ * handle must not be used from two streams or two host threads at the same time (the
+ * reference's loop is single-threaded and blocking, C6:416-465); different handles are
+ * independent.  The handle remembers the device it was created on; every call makes
+ * that device current for its own duration, and all buffers and the stream passed to a
+ * call must belong to it.
  */
 #ifndef NMPC_H_
 #define NMPC_H_
@@ -51,7 +58,7 @@ extern "C" {
  * AS/third_scenario_mpc_obstacle_avoidance.py:58,97-119,175-177).
  */
 typedef struct nmpc_config {
-    int32_t m;              /* robots, 1..NMPC_MAX_ROBOTS                                       */
+    int32_t m;              /* robots: 1..6, 8 or 10 (the team sizes of the reference scripts); 7 and 9 -> NMPC_E_UNSUPPORTED */
     int32_t N;              /* horizon, 2..4096                                                 */
     int32_t n_obs;          /* static circular obstacles, 0..NMPC_MAX_OBSTACLES                 */
     int32_t pad_rows;       /* 1: initial g block carries M constant rows (C6:278); 0: it does not */
@@ -69,7 +76,8 @@ typedef struct nmpc_config {
     double tol;             /* 1e-8 (acceptable_tol of C6:345 == IPOPT tol)                     */
     double mu_init;         /* 0.5: initial barrier parameter (IPOPT ships 0.1; 0.5 saves ~13% iterations) */
     int32_t max_iter;       /* reference: 2000                                                  */
-    int32_t reserved;
+    int32_t pair_rows;      /* 1: pairwise collision rows present (C6:288-306); 0: the multi-robot NLP WITHOUT them
+                               (AS/mpc_online_casadi_tb3_multi_centralized.py:115-148: g has 3m(N+1) rows, no padding rows) */
 } nmpc_config_t;
 
 typedef struct nmpc_handle nmpc_handle_t;
@@ -110,6 +118,8 @@ int32_t nmpc_solve_batch(nmpc_handle_t *h, int32_t B, const double *p, const dou
  * "start of the longest solve + its length", so a caller that can rank the instances by expected effort (in a receding-horizon
  * loop: by the iteration counts of the previous control period, rank correlation 0.6-0.7) puts the long ones first.
  * order == NULL is nmpc_solve_batch.  No reference counterpart (the reference solves one instance per call, C6:432).
+ * A hint that is not a permutation (an entry out of range or repeated) is detected on the device before the solve and
+ * ignored for that call (the batch is then solved in index order): a bad hint costs time, never results or memory safety.
  */
 int32_t nmpc_solve_batch_ordered(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
                                  int32_t *status, int32_t *iters, double *kkt, const int32_t *order, void *stream);
@@ -136,12 +146,15 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
  *   odom [n][4] = (x_r, y_r, q_z, q_w) wheel-odometry pose in the robot's own start frame (q_w is carried but, as in the
  *                  reference, not used: yaw = 2 asin(q_z)),
  *   init [n][3] = (x_init, y_init, th_init) pose of that start frame in the global frame,
- *   pose [n][3] = (x, y, phi) in the global frame: [x y] = R(th_init) [x_r y_r] + [x_init y_init], phi = 2 asin(q_z) + th_init.
+ *   pose [n][3] = (x, y, phi) in the global frame: [x y] = R(th_init) [x_r y_r] + [x_init y_init], phi = th + th_init with
+ *                  th = 2 asin(q_z), or, when wrap_2pi != 0, th = modify(2 asin(q_z)): the heading wrap into [0, 2 pi) of the
+ *                  scripts without collision rows (AS/mpc_online_casadi.py:24-33: th in [-pi, 0) -> th + 2 pi); the collision-free
+ *                  scripts' modify() is the identity (C2:62-68), i.e. wrap_2pi = 0.
  * Device pointers; no handle (pure function of its inputs).  SURVEY.md 8(f) row 3.
  */
-int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, void *stream);
+int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, int32_t wrap_2pi, void *stream);
 
-/* library / kernel identification string (build flags, arch) */
+/* library / kernel identification string: version, arch, and the hash of the sources it was built from (build.py) */
 const char *nmpc_version(void);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ class CConfig(C.Structure):
                 ("v_max", C.c_double), ("w_max", C.c_double), ("xy_max", C.c_double), ("th_max", C.c_double),
                 ("rob_dim", C.c_double), ("margin", C.c_double), ("pad_value", C.c_double),
                 ("obs", C.c_double * (3 * NMPC_MAX_OBSTACLES)), ("tol", C.c_double), ("mu_init", C.c_double),
-                ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+                ("max_iter", C.c_int32), ("pair_rows", C.c_int32)]
 
 
 _lib = None
@@ -58,10 +58,26 @@ def load():
     L.nmpc_solve_batch_ordered.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch_ordered.restype = i32
     L.nmpc_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_eval_batch.restype = i32
     L.nmpc_shift_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_shift_batch.restype = i32
-    L.nmpc_odometry_batch.argtypes = [C.c_int64, vp, vp, vp, vp]; L.nmpc_odometry_batch.restype = i32
+    L.nmpc_odometry_batch.argtypes = [C.c_int64, vp, vp, vp, i32, vp]; L.nmpc_odometry_batch.restype = i32
     L.nmpc_version.argtypes = []; L.nmpc_version.restype = C.c_char_p
     _lib = L
     return L
+
+
+def describe() -> str:
+    """version string of the loaded HIP library and the line of /proc/self/maps that shows it mapped into this process
+    (printed by smoke() and the GPU test session so the run's record shows WHICH native code executed)."""
+    L = load()
+    line = ""
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libnmpc_hip.so" in ln:
+                    line = ln.strip()
+                    break
+    except OSError:
+        pass
+    return "%s | mapped: %s" % (L.nmpc_version().decode(), line or "<not found in /proc/self/maps>")
 
 
 def check(rc: int, what: str):

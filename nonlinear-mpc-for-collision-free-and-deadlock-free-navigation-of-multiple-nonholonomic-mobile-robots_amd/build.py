@@ -19,17 +19,44 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libnmpc_hip.so cannot be built")
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the sources and headers the library is built from, plus the build flags that change
+    the code; it is compiled into the library (nmpc_version()) so a stale or foreign binary is recognisable."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode()); h.update(f.read())
+    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON"):
+        h.update((k + "=" + os.environ.get(k, "")).encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash() -> str:
+    """the src= tag inside the existing library ('' when absent); read from the file, the library is not loaded."""
+    if not os.path.exists(SO):
+        return ""
+    import re
+    with open(SO, "rb") as f:
+        m = re.search(rb"one wavefront per swarm instance\) src=([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else ""
+
+
 def needs_build() -> bool:
+    """True when the library is missing or was built from other sources.  Where the sources are not available (they always
+    travel with the repository) the existing library is used as it is."""
     if not os.path.exists(SO):
         return True
-    t = os.path.getmtime(SO)
-    return any(os.path.exists(os.path.join(CSRC, d)) and os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    if not all(os.path.exists(os.path.join(CSRC, d)) for d in DEPS):
+        return False
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc(), "--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", "-shared", "-o", SO] + SOURCES
+    cmd = [_hipcc(), "--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", "-shared",
+           '-DNMPC_SRC_HASH="%s"' % source_hash(), "-o", SO] + SOURCES
     if os.environ.get("NMPC_PROFILE"):
         cmd.insert(1, "-DNMPC_PROFILE")
     if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30

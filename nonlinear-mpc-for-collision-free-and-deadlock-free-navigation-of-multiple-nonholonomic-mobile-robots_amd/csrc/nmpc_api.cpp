@@ -17,17 +17,31 @@ struct nmpc_handle {
     int64_t ws_bytes;
     int kernel;          // 2 = LDS-resident wave-per-instance kernel (default), 1 = HBM-resident workgroup kernel
     long long *prof;     // device counters of the NMPC_PROFILE build (12 x int64), else unused
+    int device;          // device the workspace lives on; made current for the duration of every call
+    int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
+};
+
+// makes the handle's device current for one call and restores the caller's on return
+struct DeviceScope {
+    int prev = -1; bool ok = true, switched = false;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; switched = ok; }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 
 static bool m_supported(int m) { return (m >= 1 && m <= 6) || m == 8 || m == 10; }
 
 extern "C" {
 
-int32_t nmpc_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * c->m * c->N; }
-int32_t nmpc_n_p(const nmpc_config_t *c) { return 6 * c->m; }
+int32_t nmpc_n_var(const nmpc_config_t *c) { return c ? 3 * c->m * (c->N + 1) + 2 * c->m * c->N : NMPC_E_ARG; }
+int32_t nmpc_n_p(const nmpc_config_t *c) { return c ? 6 * c->m : NMPC_E_ARG; }
 int32_t nmpc_n_g(const nmpc_config_t *c)
 {
-    int M = c->m * (c->m - 1) / 2;
+    if (!c) return NMPC_E_ARG;
+    int M = c->pair_rows ? c->m * (c->m - 1) / 2 : 0;
     return 3 * c->m + (c->pad_rows ? M : 0) + (3 * c->m + M + c->m * c->n_obs) * c->N;
 }
 
@@ -40,14 +54,14 @@ void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
     c->r[0] = 0.5; c->r[1] = 0.05;
     c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
     c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
-    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000;
+    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000; c->pair_rows = 1;
 }
 
 static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
 {
     memset(P, 0, sizeof(*P));
-    const int m = c->m, N = c->N, nx = 3 * m, nu = 2 * m, M = m * (m - 1) / 2, K = c->n_obs;
-    P->m = m; P->N = N; P->K = K;
+    const int m = c->m, N = c->N, nx = 3 * m, nu = 2 * m, M = c->pair_rows ? m * (m - 1) / 2 : 0, K = c->n_obs;
+    P->m = m; P->N = N; P->K = K; P->pairs = (c->pair_rows && m > 1) ? 1 : 0;
     P->thb = isfinite(c->th_max) ? 1 : 0;
     P->nxb = m * (P->thb ? 3 : 2);
     P->nh = 2 * nu + 2 * P->nxb + M + m * K;
@@ -80,11 +94,18 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     if (cfg->N < 2 || cfg->N > 4096 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
     if (!(cfg->T > 0.0) || !(cfg->v_max > 0.0) || !(cfg->w_max > 0.0) || !(cfg->xy_max > 0.0) || !(cfg->th_max > 0.0)) return NMPC_E_ARG;
     if (!(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0) return NMPC_E_ARG;
+    // weights: Q >= 0, R > 0 (a non-positive R makes every Quu indefinite: it would only surface as status 2 per instance);
+    // distances and margins are lengths
+    if (!(cfg->q[0] >= 0.0) || !(cfg->q[1] >= 0.0) || !(cfg->q[2] >= 0.0) || !(cfg->r[0] > 0.0) || !(cfg->r[1] > 0.0)) return NMPC_E_ARG;
+    if (!(cfg->dmin >= 0.0) || (cfg->n_obs > 0 && (!(cfg->rob_dim >= 0.0) || !(cfg->margin >= 0.0)))) return NMPC_E_ARG;
+    for (int o = 0; o < cfg->n_obs; o++) if (!(cfg->obs[3 * o + 2] >= 0.0)) return NMPC_E_ARG;
+    if (cfg->pad_rows && !cfg->pair_rows) return NMPC_E_ARG;      // the padding rows only exist next to pair rows (C6:278)
     if (!m_supported(cfg->m)) return NMPC_E_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;   // fail loudly: no CPU path exists
     nmpc_handle *h = (nmpc_handle *)calloc(1, sizeof(nmpc_handle));
     if (!h) return NMPC_E_NOMEM;
+    if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
     h->cfg = *cfg;
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
@@ -98,6 +119,8 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
     if (hipMalloc((void **)&h->prof, (12 + 24 * 2048) * sizeof(long long)) != hipSuccess) { (void)hipFree(h->ws); free(h); return NMPC_E_NOMEM; }
     (void)hipMemset(h->prof, 0, (12 + 24 * 2048) * sizeof(long long));
+    if (hipMalloc((void **)&h->ord_chk, sizeof(int32_t) * ((size_t)max_batch + 1)) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); free(h); return NMPC_E_NOMEM; }
+    (void)hipMemset(h->ord_chk, 0, sizeof(int32_t) * ((size_t)max_batch + 1));
     { const char *ti = getenv("NMPC_TRACE_INST"); h->P.trace_inst = ti ? atoi(ti) : -1; }
     *out = h;
     return NMPC_OK;
@@ -108,6 +131,7 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
     if (!h) return NMPC_E_ARG;
     if (h->ws) (void)hipFree(h->ws);
     if (h->prof) (void)hipFree(h->prof);
+    if (h->ord_chk) (void)hipFree(h->ord_chk);
     free(h);
     return NMPC_OK;
 }
@@ -120,8 +144,12 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     if (!h || B < 0 || B > h->max_batch) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;      /* empty batch: nothing to read or write, pointers may be null */
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
+    DeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
     nmpc::KParams P = h->P;
     P.order = order;
+    P.order_bad = h->ord_chk + B;
+    if (order && nmpc::launch_order_check(B, order, h->ord_chk, h->ord_chk + B, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
     hipError_t e = (h->kernel == 1)
                        ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                        : nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
@@ -145,6 +173,8 @@ int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const doub
     if (!h || B < 0) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;
     if (!p || !w) return NMPC_E_ARG;
+    DeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
     hipError_t e = nmpc::launch_eval(h->P, h->cfg.m, B, p, w, f, g, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
@@ -155,18 +185,20 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
     if (B == 0) return NMPC_OK;
     if (!w_in || !w_next || w_in == w_next) return NMPC_E_ARG;
     if (x0_next && !p_in) return NMPC_E_ARG;
+    DeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
     hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
-int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, void *stream)
+int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, double *pose, int32_t wrap_2pi, void *stream)
 {
     if (n < 0) return NMPC_E_ARG;
     if (n == 0) return NMPC_OK;
     if (!odom || !init || !pose) return NMPC_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;
-    return nmpc::launch_odometry((long)n, odom, init, pose, (hipStream_t)stream) == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+    return nmpc::launch_odometry((long)n, odom, init, pose, wrap_2pi != 0, (hipStream_t)stream) == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
 /* development aid (not part of include/nmpc.h): per-phase cycle counters of an NMPC_PROFILE build */
@@ -205,6 +237,9 @@ int64_t nmpc_debug_workspace(nmpc_handle_t *h, int32_t inst, double *out, int64_
     return per;
 }
 
-const char *nmpc_version(void) { return "nmpc_hip 0.1 (gfx950, fp64, one workgroup per instance)"; }
+#ifndef NMPC_SRC_HASH
+#define NMPC_SRC_HASH "unknown"
+#endif
+const char *nmpc_version(void) { return "nmpc_hip 0.2 (gfx950, fp64, one wavefront per swarm instance) src=" NMPC_SRC_HASH; }
 
 }  // extern "C"

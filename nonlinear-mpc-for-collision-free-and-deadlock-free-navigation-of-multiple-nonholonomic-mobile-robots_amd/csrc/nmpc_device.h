@@ -16,8 +16,10 @@ struct KParams {
     double obs[3 * NMPC_MAX_OBSTACLES];
     // per-instance workspace carve-up, in doubles
     int64_t stride;
-    int32_t trace_inst, pad_;   // NMPC_PROFILE builds: instance whose per-iteration trace is recorded
+    int32_t trace_inst;   // NMPC_PROFILE builds: instance whose per-iteration trace is recorded
+    int32_t pairs;        // 1: pair rows present (C6:288-306); 0: multi-robot NLP without them (mpc_online_casadi_tb3_multi_centralized.py)
     const int32_t *order;       // per call: dispatch order (workgroup g solves instance order[g]) or nullptr = identity
+    const int32_t *order_bad;   // device flag written by the permutation check of that order: non-zero -> the hint is ignored
     int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
     int64_t oPACK, oKT;
     int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;
@@ -31,6 +33,7 @@ size_t lds_kernel_bytes(const KParams &P, int m);
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);
-hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, hipStream_t st);
+hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, int wrap, hipStream_t st);
+hipError_t launch_order_check(int B, const int32_t *order, int32_t *count, int32_t *bad, hipStream_t st);
 
 }  // namespace nmpc

@@ -141,7 +141,7 @@ __device__ __forceinline__ void jxT_robot(const KParams &P, int k, int i, const 
     if (k > P.N - 1) return;
     const double xi = x[3 * i], yi = x[3 * i + 1];
 #pragma unroll
-    for (int j = 0; j < M_; j++) {
+    for (int j = 0; j < (P.pairs ? M_ : 0); j++) {
         if (j == i) continue;
         int pq = (i < j) ? pair_index<M_>(i, j) : pair_index<M_>(j, i);
         double z = v(P.o_pr + pq);
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     const int tid = threadIdx.x;
     const int N = P.N, NH = P.nh;
     const double T = P.T;
-    const size_t inst = P.order ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;
+    const size_t inst = (P.order && *P.order_bad == 0) ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;
+    const int NPA = P.pairs ? NP : 0;
 
     __shared__ double sP[NX * NX];   // P_{k+1}, then Qxx, then P_k
     __shared__ double sG[NX * NZ];   // P [A B]
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     // ---- stage-0 pair / obstacle rows act on the pinned state: feasibility pre-check
     {
         double bad = 0.0;
-        for (int q = tid; q < NP; q += TPB) {
+        for (int q = tid; q < NPA; q += TPB) {
             int i = sPi[q], j = sPj[q];
             double dx = pp[3 * i] - pp[3 * j], dy = pp[3 * i + 1] - pp[3 * j + 1];
             if (dx * dx + dy * dy < P.dmin2) bad = 1.0;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                     for (int q = tid; q < NP; q += TPB) {
                         int i = sPi[q], j = sPj[q];
                         double dx = sX[3 * i] - sX[3 * j], dy = sX[3 * i + 1] - sX[3 * j + 1];
-                        double zz = Z[k * NH + P.o_pr + q], sg = zz / S[k * NH + P.o_pr + q];
+                        double zz = P.pairs ? Z[k * NH + P.o_pr + q] : 0.0, sg = P.pairs ? zz / S[k * NH + P.o_pr + q] : 0.0;
                         sE[3 * q] = 4 * sg * dx * dx - 2 * zz; sE[3 * q + 1] = 4 * sg * dx * dy; sE[3 * q + 2] = 4 * sg * dy * dy - 2 * zz;
                     }
                 }
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                     // exact-Hessian terms of the pair / obstacle rows: -z hess(h) dx
                     double w0_ = 0.0, w1_ = 0.0;
 #pragma unroll
-                    for (int j = 0; j < M_; j++) {
+                    for (int j = 0; j < (P.pairs ? M_ : 0); j++) {
                         if (j == i) continue;
                         int q = (i < j) ? pair_index<M_>(i, j) : pair_index<M_>(j, i);
                         double zz = zk[P.o_pr + q];
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void eval_kernel(const KParams P, int B, const
     if (k == N) {
         if (g) {
             for (int c = 0; c < NX; c++) g[c] = X[c] - pp[c];
-            if (P.pad_rows) for (int c = 0; c < NP; c++) g[NX + c] = P.pad_value;
+            if (P.pad_rows && P.pairs) for (int c = 0; c < NP; c++) g[NX + c] = P.pad_value;
         }
         return;
     }
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(256) void eval_kernel(const KParams P, int B, const
     }
     if (gk) {
         int o = NX;
-        for (int i = 0; i < M_; i++)
+        for (int i = 0; i < (P.pairs ? M_ : 0); i++)
             for (int j = i + 1; j < M_; j++) {
                 double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
                 gk[o++] = dx * dx + dy * dy;
@@ -925,7 +926,7 @@ template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, cons
 // ------------------------------------------------------------------------------------------
 // Odometry front-end (C2:18-37): per robot, wheel-odometry pose in the robot's start frame -> pose in the global frame.
 //   th = 2 asin(q_z); phi = th + th_init; [x y] = R(th_init) [x_r y_r] + [x_init y_init].   Streaming, 7 doubles in, 3 out.
-__global__ __launch_bounds__(256) void odometry_kernel(long n, const double *__restrict__ odom, const double *__restrict__ init, double *__restrict__ pose)
+__global__ __launch_bounds__(256) void odometry_kernel(long n, const double *__restrict__ odom, const double *__restrict__ init, double *__restrict__ pose, int wrap)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -935,11 +936,39 @@ __global__ __launch_bounds__(256) void odometry_kernel(long n, const double *__r
     sincos(thi, &s, &c);
     pose[3 * i] = (c * xr - s * yr) + xi;
     pose[3 * i + 1] = (s * xr + c * yr) + yi;
-    pose[3 * i + 2] = 2.0 * asin(qz) + thi;
+    double th = 2.0 * asin(qz);
+    // modify() of the scripts without collision rows (AS/mpc_online_casadi.py:28-33): th in [-pi, 0) -> th + 2 pi
+    if (wrap && th >= -3.14159265358979323846 && th < 0.0) th += 2.0 * 3.14159265358979323846;
+    pose[3 * i + 2] = th + thi;
 }
-hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, hipStream_t st)
+hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, int wrap, hipStream_t st)
 {
-    hipLaunchKernelGGL(odometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, odom, init, pose);
+    hipLaunchKernelGGL(odometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, odom, init, pose, wrap);
+    return hipGetLastError();
+}
+
+// Permutation check of a dispatch-order hint (nmpc_solve_batch_ordered): count[o]++ for every entry, then any count != 1 (or an
+// entry outside 0..B-1) raises *bad; the solve kernels ignore the hint when *bad != 0.  Three tiny launches on the call's stream.
+__global__ __launch_bounds__(256) void order_count_kernel(int B, const int32_t *__restrict__ order, int32_t *__restrict__ count, int32_t *__restrict__ bad)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B) return;
+    const int o = order[g];
+    if (o < 0 || o >= B) atomicOr(bad, 1);
+    else atomicAdd(&count[o], 1);
+}
+__global__ __launch_bounds__(256) void order_verify_kernel(int B, const int32_t *__restrict__ count, int32_t *__restrict__ bad)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < B && count[g] != 1) atomicOr(bad, 1);
+}
+hipError_t launch_order_check(int B, const int32_t *order, int32_t *count, int32_t *bad, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)(B + 1), st);      // count[B] is the flag
+    if (e != hipSuccess) return e;
+    const unsigned nb = (unsigned)((B + 255) / 256);
+    hipLaunchKernelGGL(order_count_kernel, dim3(nb), dim3(256), 0, st, B, order, count, bad);
+    hipLaunchKernelGGL(order_verify_kernel, dim3(nb), dim3(256), 0, st, B, count, bad);
     return hipGetLastError();
 }
 

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     const int tid = threadIdx.x;
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
-    const size_t inst = P.order ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;      // dispatch-order hint: long solves first
+    const size_t inst = (P.order && *P.order_bad == 0) ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;      // dispatch-order hint: long solves first (ignored unless it is a permutation)
+    const bool prs = P.pairs != 0;                 // pair rows present (the no-pair multi-robot NLP keeps NP slots that are never touched)
+    const int NPA = prs ? G::NP : 0;
 
     extern __shared__ double sm[];
     double *X = sm;                       // [N1*NX]
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     // ---- stage-0 pair / obstacle rows act on the pinned state: feasibility pre-check
     {
         double bad = 0.0;
-        for (int q = tid; q < NP; q += TPB) {
+        for (int q = tid; q < NPA; q += TPB) {
             int i = 0, r = q;
             while (r >= M_ - 1 - i) { r -= M_ - 1 - i; i++; }
             int j = i + 1 + r;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             l += log(n0 + P.xymax) + log(P.xymax - n0) + log(n1 + P.xymax) + log(P.xymax - n1);
             if (THB) l += log(n2 + P.thmax) + log(P.thmax - n2);
         }
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     auto init_barrier = [&]() {
         for (int it = tid; it < N1 * NP; it += TPB) {
             int k = it / NPd, q = it - k * NP;
-            if (k >= 1 && k <= N - 1) {
+            if (k >= 1 && k <= N - 1 && prs) {
                 int i, j; pair_ij(q, i, j);
                 double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
                 double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (kk <= N - 1) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
 #pragma unroll 1
-                for (int j = 0; j < M_; j++) {
+                for (int j = 0; j < (prs ? M_ : 0); j++) {
                     if (j == i) continue;
                     int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
                     double z = ZPp[kk * NP + q];
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double p0 = SUL[k * NU + 2 * i] * zl0, p1 = SUU[k * NU + 2 * i] * zu0, p2 = SUL[k * NU + 2 * i + 1] * zl1, p3 = SUU[k * NU + 2 * i + 1] * zu1;
             szmax = fmax(szmax, fmax(fmax(p0, p1), fmax(p2, p3))); szmin = fmin(szmin, fmin(fmin(p0, p1), fmin(p2, p3)));
         }
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             double zv = ZPp[NP + it], pz = SPp[NP + it] * zv;
             zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
         }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 if (k <= N - 1) {
                     const double xi = x[3 * i], yi = x[3 * i + 1];
 #pragma unroll 1
-                    for (int j = 0; j < M_; j++) {
+                    for (int j = 0; j < (prs ? M_ : 0); j++) {
                         if (j == i) continue;
                         int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
                         double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             pk[G::PK_HXY + i] = hxy;
         }
         // (b) pair blocks E_ij = 4 sigma dp dp^T - 2 z I per (stage, pair)
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
@@ -667,6 +669,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
         }
         for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
+        if (!prs)                                                              // no pair rows at all: the E slots of every stage are zero
+            for (int e = tid; e < (N - 1) * 3 * NP; e += TPB) gpack[(size_t)(1 + e / (3 * NPd)) * G::PACK + G::PK_E + e % (3 * NPd)] = 0.0;
         __syncthreads();
         PROF_T(2);
 
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = v + b, su = b - v;
             fb(sl, ZXL[k * NXB + s], dv + ((v + b) - sl)); fb(su, ZXU[k * NXB + s], -dv + ((b - v) - su));
         }
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (k < N) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
 #pragma unroll 1
-                for (int j = 0; j < M_; j++) {
+                for (int j = 0; j < (prs ? M_ : 0); j++) {
                     if (j == i) continue;
                     int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
                     double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                 }
             }
         }
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
@@ -1132,7 +1136,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             ZXL[es] = zup(sl, ZXL[es], dv + ((v + b) - sl), sn);
             ZXU[es] = zup(su, ZXU[es], -dv + ((b - v) - su), sn);
         }
-        for (int it = tid; it < (N - 1) * NP; it += TPB) {
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
@@ -1219,9 +1223,11 @@ template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B,
     // Latency shape (five and six robots): a batch that leaves most of the chip idle is solved with 2 or 4 waves per instance —
     // measured 189 / 148 / 139 us per iteration at 64 / 128 / 256 threads (m=6, N=20, one instance per CU).  This is the
     // reference's own use (one swarm per control period) and the tail of small closed-loop batches.
+    // (the wider shapes carry a larger 16-bit element table: a horizon that only fits the 160 KB of LDS in the throughput
+    // shape stays on it)
     if constexpr (M_ == 5 || M_ == 6) {
-        if (B <= 256) return launch2_mtt<M_, THB, 256>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-        if (B <= 512) return launch2_mtt<M_, THB, 128>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+        if (B <= 256 && lds_bytes<M_, THB>(P, 256) <= (size_t)160 * 1024) return launch2_mtt<M_, THB, 256>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+        if (B <= 512 && lds_bytes<M_, THB>(P, 128) <= (size_t)160 * 1024) return launch2_mtt<M_, THB, 128>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     }
     constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
     return launch2_mtt<M_, THB, TPB>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);

@@ -31,6 +31,7 @@ class ProblemConfig:
     margin: float = 0.1
     pad_value: float = 3.5                               # C6:278
     pad_rows: bool = True
+    pair_rows: bool = True                               # False: AS/mpc_online_casadi_tb3_multi_centralized.py:115-148 (no collision rows)
     # 'ipopt' options of C6:345 that the solve honours
     tol: float = 1e-8
     mu_init: float = 0.5
@@ -41,7 +42,7 @@ class ProblemConfig:
     @property
     def nu(self): return 2 * self.m
     @property
-    def M(self): return self.m * (self.m - 1) // 2
+    def M(self): return self.m * (self.m - 1) // 2 if self.pair_rows else 0
     @property
     def n_var(self): return self.nx * (self.N + 1) + self.nu * self.N
     @property
@@ -65,6 +66,7 @@ class ProblemConfig:
         for i, (ox, oy, orad) in enumerate(self.obstacles):
             c.obs[3 * i], c.obs[3 * i + 1], c.obs[3 * i + 2] = ox, oy, orad
         c.tol, c.mu_init, c.max_iter = self.tol, self.mu_init, self.max_iter
+        c.pair_rows = int(self.pair_rows)
         return c
 
     # bounds exactly as the scripts build them (C6:349-352; third_scenario_mpc_obstacle_avoidance.py:175-177)
@@ -91,6 +93,9 @@ def centralized_two_robots(N: int = 70) -> ProblemConfig:        # AS/centralize
 
 def centralized_six_robots(N: int = 35) -> ProblemConfig:        # C6:197-205
     return ProblemConfig(m=6, N=N, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
+
+def two_robots_no_collision_rows(N: int = 50) -> ProblemConfig:  # AS/mpc_online_casadi_tb3_multi_centralized.py:60-66,115-148
+    return ProblemConfig(m=2, N=N, T=0.01, dmin=0.0, v_max=0.22, w_max=2.84, pad_rows=False, pair_rows=False)
 
 def ten_robots_collision_avoidance(N: int = 20) -> ProblemConfig:  # AS/mpc_online_casadi_tb3_ten_multi_centralized_collision_avoidance.py:169-177
     return ProblemConfig(m=10, N=N, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84)

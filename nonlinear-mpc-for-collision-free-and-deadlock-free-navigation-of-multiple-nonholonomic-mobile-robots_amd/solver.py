@@ -46,9 +46,10 @@ def cold_start(cfg: ProblemConfig, x0) -> np.ndarray:
     return np.concatenate([np.tile(x0, cfg.N + 1), np.zeros(cfg.nu * cfg.N)])
 
 
-def odometry_to_global(odom, init, device=None):
+def odometry_to_global(odom, init, device=None, wrap_2pi: bool = False):
     """Batched odometry callback of the scripts (C2:18-37): odom [n,4] = (x_r, y_r, q_z, q_w), init [n,3] = (x, y, th) of the
-    robot's start frame -> pose [n,3] in the global frame (device tensor).  Runs nmpc_odometry_batch."""
+    robot's start frame -> pose [n,3] in the global frame (device tensor).  Runs nmpc_odometry_batch.
+    wrap_2pi: the modify() of the scripts without collision rows (AS/mpc_online_casadi.py:24-33), yaw in [-pi,0) -> +2 pi."""
     torch = _torch()
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -58,7 +59,7 @@ def odometry_to_global(odom, init, device=None):
         raise ValueError(f"odom has {o.shape[0]} rows, init {i0.shape[0]}")
     pose = torch.empty((o.shape[0], 3), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.nmpc_odometry_batch(o.shape[0], o.data_ptr(), i0.data_ptr(), pose.data_ptr(), torch.cuda.current_stream().cuda_stream), "nmpc_odometry_batch")
+        _lib.check(lib.nmpc_odometry_batch(o.shape[0], o.data_ptr(), i0.data_ptr(), pose.data_ptr(), int(bool(wrap_2pi)), torch.cuda.current_stream().cuda_stream), "nmpc_odometry_batch")
     return pose
 
 

@@ -45,13 +45,14 @@ class NLPConfig:
     margin: float = 0.1              # lbg of obstacle rows (O3:175)
     pad_value: float = 3.5           # constant rows of the initial block (C6:278)
     pad_rows: bool = True            # C6:278 pads; the 1-robot files (C1:108, O3:122) do not
+    pair_rows: bool = True           # False: multi-robot NLP without collision rows (AS/mpc_online_casadi_tb3_multi_centralized.py:115-148)
 
     @property
     def nx(self): return 3 * self.m
     @property
     def nu(self): return 2 * self.m
     @property
-    def M(self): return self.m * (self.m - 1) // 2
+    def M(self): return self.m * (self.m - 1) // 2 if self.pair_rows else 0
     @property
     def K(self): return len(self.obstacles)
     @property
@@ -69,7 +70,7 @@ class NLPConfig:
 
     def pairs(self):
         """lexicographic i<j order 12,13,...,1m,23,... (C6:288-306)."""
-        return [(i, j) for i in range(self.m) for j in range(i + 1, self.m)]
+        return [(i, j) for i in range(self.m) for j in range(i + 1, self.m)] if self.pair_rows else []
 
 
 # ----------------------------------------------------------------------------
@@ -305,6 +306,9 @@ def cfg_two(N=20):   # C2:101-109
 def cfg_six(N=20):   # C6:197-205
     return NLPConfig(m=6, N=N, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
 
+def cfg_two_nopairs(N=50):   # AS/mpc_online_casadi_tb3_multi_centralized.py:60-66,115-148: m=2, T=0.01, N=50, no pair rows, no padding rows
+    return NLPConfig(m=2, N=N, T=0.01, dmin=0.0, v_max=0.22, w_max=2.84, pad_rows=False, pair_rows=False)
+
 def cfg_ten(N=30):   # C10:169-177
     return NLPConfig(m=10, N=N, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84)
 
@@ -323,11 +327,14 @@ C6_GOAL = np.array([-0.7, -0.4, -2.618, 0.0, -0.8, -1.57, 0.7, -0.4, -0.523,
                     0.7, 0.4, 0.523, 0.0, 0.8, 1.57, -0.7, 0.4, 2.618])      # C6:386-388
 
 
-def odom_to_global(odom, init):
+def odom_to_global(odom, init, wrap_2pi=False):
     """Odometry callbacks of the scripts (C2:18-37): odom [n,4] = (x_r, y_r, q_z, q_w) in the robot's start frame,
-    init [n,3] = (x_init, y_init, th_init) -> pose [n,3] in the global frame.  q_w is not used by the reference either."""
+    init [n,3] = (x_init, y_init, th_init) -> pose [n,3] in the global frame.  q_w is not used by the reference either.
+    wrap_2pi: modify() of AllScripts/mpc_online_casadi.py:24-33 (th in [-pi, 0) -> th + 2 pi); identity in C2:62-68."""
     odom = np.asarray(odom, dtype=np.float64).reshape(-1, 4); init = np.asarray(init, dtype=np.float64).reshape(-1, 3)
     th = 2.0 * np.arcsin(odom[:, 2])
+    if wrap_2pi:
+        th = np.where((th >= -np.pi) & (th < 0.0), th + 2.0 * np.pi, th)
     c, s = np.cos(init[:, 2]), np.sin(init[:, 2])
     x = (c * odom[:, 0] - s * odom[:, 1]) + init[:, 0]
     y = (s * odom[:, 0] + c * odom[:, 1]) + init[:, 1]

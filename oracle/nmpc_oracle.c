@@ -72,7 +72,7 @@ int32_t nmpc_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * 
 int32_t nmpc_n_p(const nmpc_config_t *c) { return 6 * c->m; }
 int32_t nmpc_n_g(const nmpc_config_t *c)
 {
-    int M = c->m * (c->m - 1) / 2;
+    int M = c->pair_rows ? c->m * (c->m - 1) / 2 : 0;   /* pair_rows = 0: AS/mpc_online_casadi_tb3_multi_centralized.py:115-148 */
     return 3 * c->m + (c->pad_rows ? M : 0) + (3 * c->m + M + c->m * c->n_obs) * c->N;
 }
 
@@ -85,14 +85,14 @@ void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
     c->r[0] = 0.5; c->r[1] = 0.05;
     c->v_max = 0.22; c->w_max = 2.84; c->xy_max = 10.0; c->th_max = INFINITY;
     c->rob_dim = 0.2; c->margin = 0.1; c->pad_value = 3.5;
-    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000;
+    c->tol = 1e-8; c->mu_init = 0.5; c->max_iter = 2000; c->pair_rows = 1;
 }
 
 static ws_t *ws_new(const nmpc_config_t *c)
 {
     ws_t *w = (ws_t *)calloc(1, sizeof(ws_t));
     int m = c->m, N = c->N;
-    w->m = m; w->N = N; w->K = c->n_obs; w->nx = 3 * m; w->nu = 2 * m; w->M = m * (m - 1) / 2;
+    w->m = m; w->N = N; w->K = c->n_obs; w->nx = 3 * m; w->nu = 2 * m; w->M = c->pair_rows ? m * (m - 1) / 2 : 0;
     w->thb = isfinite(c->th_max) ? 1 : 0;
     w->trace = getenv("NMPC_ORACLE_TRACE") != NULL;
     w->max_restarts = getenv("NMPC_ORACLE_MAX_RESTARTS") ? atoi(getenv("NMPC_ORACLE_MAX_RESTARTS")) : 3;
@@ -728,7 +728,7 @@ int32_t nmpc_oracle_solve_batch(const nmpc_config_t *cfg, int32_t B, const doubl
 /* f and g in the reference's row order (C6:278,314,318-331) */
 int32_t nmpc_oracle_eval_batch(const nmpc_config_t *cfg, int32_t B, const double *p, const double *wv, double *f, double *g)
 {
-    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, M = m * (m - 1) / 2, K = cfg->n_obs;
+    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, M = cfg->pair_rows ? m * (m - 1) / 2 : 0, K = cfg->n_obs;
     const int nv = nmpc_n_var(cfg), ng = nmpc_n_g(cfg);
     for (int b = 0; b < B; b++) {
         const double *X = wv + (size_t)b * nv, *U = X + (size_t)(N + 1) * nx, *pp = p + (size_t)b * 2 * nx;
@@ -751,7 +751,7 @@ int32_t nmpc_oracle_eval_batch(const nmpc_config_t *cfg, int32_t B, const double
                 }
             }
             if (gg) {
-                for (int i = 0; i < m; i++)
+                for (int i = 0; i < (M ? m : 0); i++)
                     for (int j = i + 1; j < m; j++) {
                         double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
                         gg[o++] = dx * dx + dy * dy;

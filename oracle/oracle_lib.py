@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ("v_max", C.c_double), ("w_max", C.c_double), ("xy_max", C.c_double), ("th_max", C.c_double),
                 ("rob_dim", C.c_double), ("margin", C.c_double), ("pad_value", C.c_double),
                 ("obs", C.c_double * 24), ("tol", C.c_double), ("mu_init", C.c_double),
-                ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+                ("max_iter", C.c_int32), ("pair_rows", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -60,6 +60,7 @@ def make_config(nlp_cfg, tol=1e-8, mu_init=0.5, max_iter=2000) -> Config:
     for i, (ox, oy, orad) in enumerate(nlp_cfg.obstacles):
         c.obs[3 * i], c.obs[3 * i + 1], c.obs[3 * i + 2] = ox, oy, orad
     c.tol, c.mu_init, c.max_iter = tol, mu_init, max_iter
+    c.pair_rows = int(getattr(nlp_cfg, "pair_rows", True))
     return c
 
 

@@ -50,13 +50,27 @@ def make(name, cfg, P):
 
 
 if __name__ == "__main__":
+    # usage: gen_golden.py [name ...]   (default: the four small sets; "six" takes ~8 min, "ten" ~25 min of one core)
+    want = sys.argv[1:] or ["one", "two", "obs3", "three"]
     rng = np.random.Generator(np.random.PCG64(Hh.SEED0))
     c1 = R.cfg_one(20)
-    make("one", c1, [np.array([0.0, 0.0, 0.0, 1.5, 1.5, 0.0])] + [Hh.instance(rng, c1) for _ in range(5)])   # C1:177 first goal
+    P1 = [np.array([0.0, 0.0, 0.0, 1.5, 1.5, 0.0])] + [Hh.instance(rng, c1) for _ in range(5)]   # C1:177 first goal
     c2 = R.cfg_two(20)
     close = np.array([-0.2, 0.0, 0.0, 0.2, 0.02, np.pi, 0.6, 0.0, 0.0, -0.6, 0.0, np.pi])
-    make("two", c2, [np.concatenate([R.C2_START, R.C2_GOAL]), close] + [Hh.instance(rng, c2) for _ in range(4)])
+    P2 = [np.concatenate([R.C2_START, R.C2_GOAL]), close] + [Hh.instance(rng, c2) for _ in range(4)]
     co = R.cfg_obs3(20)
-    make("obs3", co, [np.array([0.0, 0.2 + 0.1 * t, 1.2, 0.2 * t, 2.6, 1.57]) for t in range(4)])
     c3 = R.NLPConfig(m=3, N=10, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
-    make("three", c3, [Hh.instance(rng, c3) for _ in range(3)])
+    P3 = [Hh.instance(rng, c3) for _ in range(3)]
+    if "one" in want: make("one", c1, P1)
+    if "two" in want: make("two", c2, P2)
+    if "obs3" in want: make("obs3", co, [np.array([0.0, 0.2 + 0.1 * t, 1.2, 0.2 * t, 2.6, 1.57]) for t in range(4)])
+    if "three" in want: make("three", c3, P3)
+    # the headline configuration (BASELINE configs[2]): the literal antipodal swap of C6:364-388 plus four drawn instances,
+    # and two ten-robot instances at the file's own horizon N=20; own generator streams so that the
+    # small sets above stay byte-identical
+    if "six" in want:
+        c6 = R.cfg_six(20); r6 = np.random.Generator(np.random.PCG64(Hh.SEED0 + 600))
+        make("six", c6, [np.concatenate([R.C6_START, R.C6_GOAL])] + [Hh.instance(r6, c6) for _ in range(4)])
+    if "ten" in want:
+        c10 = R.cfg_ten(20); r10 = np.random.Generator(np.random.PCG64(Hh.SEED0 + 1000))
+        make("ten", c10, [Hh.instance(r10, c10) for _ in range(2)])

@@ -4,9 +4,11 @@ Tolerances (fp64 path, north_star "within a stated FP tolerance"):
   * same-basin instances: max |w_hip - w_oracle| <= 1e-6 (m, rad, m/s, rad/s); |f_hip - f_oracle| <= 1e-6 * max(1,|f|)
   * every instance: reported KKT error <= tol = 1e-8, and for a sample the independent
     least-squares KKT check of oracle/nlp_ref.kkt_report.
-The NLP is non-convex: two correct solvers may land in different local minima,
-so the iterate-level comparison is required on >= 85 % of a random batch, the rest must be
-valid KKT points themselves.
+The NLP is non-convex: two correct solvers may land in different local minima; the HIP path and the
+oracle run the same algorithm, so in practice they land in the same one.  Thresholds are set at what is measured
+(same basin 100 % on these batches), with one instance of slack on the large batches: SAME_FRAC.  An instance in
+another basin must be a valid KKT point itself (independent least-squares check, run on EVERY instance of the
+six- and ten-robot batches, not only on those).
 """
 import numpy as np
 import pytest
@@ -18,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 W_TOL = 1e-6
 F_RTOL = 1e-6
+SAME_FRAC = 0.99          # measured 1.000 (GPUTEST_r01); 0.99 leaves one instance per 100 of slack for a chaotic tail solve
 
 
 def _solver(ocfg, B, max_iter=400):
@@ -50,13 +53,19 @@ def test_solve_matches_oracle(built, name, ocfg, B, idx):
     same = dw <= W_TOL
     frac = same.mean()
     print(f"{name}: same-basin {frac:.3f}, iters hip mean {r['iters'].mean():.1f} max {r['iters'].max()}, oracle mean {ref['iters'].mean():.1f}")
-    assert frac >= 0.85, (name, frac, dw)
+    assert frac >= SAME_FRAC, (name, frac, dw)
+    assert (r["iters"] == ref["iters"]).mean() >= 0.9, (r["iters"], ref["iters"])      # same algorithm: same iteration counts
     rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
     assert (rel[same] <= F_RTOL).all()
-    # instances that ended in another basin must still be KKT points (independent check)
-    for b in np.where(~same)[0][:4]:
+    # independent KKT check of the HIP output (least-squares multipliers on the active set, oracle/nlp_ref.kkt_report):
+    # every instance of the six- and ten-robot batches, and any instance that ended in another basin
+    chk = range(B) if name in ("six", "ten") else np.where(~same)[0]
+    worst = dict(stat=0.0, eq=0.0, ineq=0.0, bnd=0.0)
+    for b in chk:
         k = R.kkt_report(ocfg, r["x"][b], P[b], tol_active=1e-3)
         assert k["stat"] < 1e-5 and k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
+        worst = {q: max(worst[q], k[q]) for q in worst}
+    print(f"{name}: kkt_report on {len(list(chk))} HIP solutions, worst {worst}")
     # x0 is pinned and bounds hold exactly
     assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
     lbx, ubx, _, _ = R.bounds(ocfg)
@@ -77,7 +86,7 @@ def test_warm_start_matches_oracle(built):
     r = _np(s.solve_batch(P2, Wn)); torch.cuda.synchronize()
     assert (r["status"] == ref["status"]).all()
     dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
-    assert (dw <= W_TOL).mean() >= 0.85, dw
+    assert (dw <= W_TOL).all(), dw
 
 
 def test_closed_loop_steps_match_oracle(built):
@@ -96,7 +105,7 @@ def test_closed_loop_steps_match_oracle(built):
         r = _np(s.solve_batch(P, W)); torch.cuda.synchronize()
         assert (ref["status"] == 0).all() and (r["status"] == 0).all(), (step, ref["status"], r["status"])
         dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
-        assert (dw <= W_TOL).mean() >= 0.85, (step, dw)
+        assert (dw <= W_TOL).mean() >= 0.97, (step, dw)      # 48 swarms: at most one in another basin per step
         Wn, x0n = O.shift_batch(oc, P, ref["x"])
         wn_d, x0n_d = s.shift_batch(P, ref["x"], plant=True)
         assert np.abs(wn_d.cpu().numpy() - Wn).max() <= 1e-12 and np.abs(x0n_d.cpu().numpy() - x0n).max() <= 1e-12
@@ -156,10 +165,10 @@ def test_file_horizons_other_team_sizes_and_composite(built, name, ocfg, B, idx)
     ref = O.solve_batch(O.make_config(ocfg, max_iter=600), P, W0)
     assert (r["status"] == ref["status"]).all(), (r["status"], ref["status"])
     conv = r["status"] == 0
-    assert conv.mean() >= 0.9
+    assert conv.all(), r["status"]
     dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
     print(f"{name}: same-basin {(dw[conv] <= W_TOL).mean():.3f}, iters hip mean {r['iters'].mean():.1f} oracle {ref['iters'].mean():.1f}")
-    assert (dw[conv] <= W_TOL).mean() >= 0.85, dw
+    assert (dw[conv] <= W_TOL).mean() >= (0.95 if B >= 24 else 0.87), dw        # at most one instance of the batch in another basin
 
 
 def test_literal_scenarios(built):
@@ -289,6 +298,13 @@ def test_odometry_front_end(built):
         assert got.shape == (n, 3)
         if n:
             assert np.abs(got - ref).max() <= 1e-14, np.abs(got - ref).max()
+            # modify() of the scripts without collision rows (AS/mpc_online_casadi.py:24-33): yaw wrapped into [0, 2 pi)
+            gw = nmpc_amd.odometry_to_global(odom, init, wrap_2pi=True).cpu().numpy()
+            rw = R.odom_to_global(odom, init, wrap_2pi=True)
+            assert np.abs(gw - rw).max() <= 1e-14
+            yaw = gw[:, 2] - init[:, 2]
+            assert (yaw >= -1e-12).all() and (yaw < 2 * np.pi + 1e-12).all()     # [-pi, 0) went to [pi, 2 pi)
+            assert np.array_equal(gw[odom[:, 2] >= 0], got[odom[:, 2] >= 0])
     # the literal first callback: robot 1 of the two-robot script starts at (-0.7112, -0.7112, 0.785) (C2:213-216)
     pose = nmpc_amd.odometry_to_global([[0.1, 0.0, np.sin(0.2 / 2), np.cos(0.2 / 2)]], [R.C2_START[:3]]).cpu().numpy()[0]
     assert np.allclose(pose, [R.C2_START[0] + 0.1 * np.cos(0.785), R.C2_START[1] + 0.1 * np.sin(0.785), 0.985], atol=1e-15)
@@ -320,7 +336,8 @@ def test_barrier_restart_rescues_composite_stalls(built):
     ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"], d["w"])
     r = _np(_solver(ocfg, len(d["p"]), max_iter=2000).solve_batch(d["p"], d["w"]))
     assert (ref["status"] == 0).mean() >= 0.75, ref["status"]
-    assert (r["status"] == ref["status"]).mean() >= 0.75, (r["status"], ref["status"])
+    # these are the chaotic cases by construction (captured stalls): one of the twelve may end differently
+    assert (r["status"] == ref["status"]).mean() >= 0.9, (r["status"], ref["status"])
     both = (r["status"] == 0) & (ref["status"] == 0)
     assert (r["kkt"][both] <= 1e-8).all()
 
@@ -350,8 +367,8 @@ def test_random_configurations_match_oracle(built):
         dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
         same = dw <= W_TOL
         tag = (t, m, N, K, cfg.th_max)
-        assert (r["status"] == ref["status"]).mean() >= 0.9, (tag, r["status"], ref["status"])
-        assert same.mean() >= 0.8, (tag, dw)
+        assert (r["status"] == ref["status"]).all(), (tag, r["status"], ref["status"])
+        assert same.mean() >= 0.9, (tag, dw)
         rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
         assert (rel[same] <= F_RTOL).all(), (tag, rel)
         assert (r["kkt"][r["status"] == 0] <= 1e-8).all(), tag

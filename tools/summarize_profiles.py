@@ -12,7 +12,7 @@ import csv, json, os, shutil, sqlite3, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
-KERNEL = "solve_lds_kernel"
+KERNEL = os.environ.get("NMPC_PROFILE_KERNEL", "solve_lds_kernel")
 
 
 def db(name):
@@ -54,6 +54,10 @@ traffic = {
     "registers": [{"kernel": s[0][:60], "lds_static": s[1], "scratch": s[2], "sgpr": s[3], "vgpr": s[4], "agpr": s[5]} for s in sym],
 }
 bj = json.load(open(os.path.join(src, "bench_fetch.json")))
+import re as _re
+_m = _re.search(r"src=([0-9a-f]{16})", bj.get("library", ""))
+traffic["library_src_hash"] = _m.group(1) if _m else None      # bench.py only uses this profile for the build it was taken from
+traffic["library"] = bj.get("library")
 traffic["total_iterations_per_launch"] = bj["solve_stats"]["mean_iters"] * bj["config"]["batch_per_gpu"]
 traffic["hbm_bytes_per_iteration"] = traffic["hbm_bytes_per_launch"] / traffic["total_iterations_per_launch"]
 traffic["hbm_GBps"] = traffic["hbm_bytes_per_launch"] / (solve[3] * 1e-9) / 1e9
