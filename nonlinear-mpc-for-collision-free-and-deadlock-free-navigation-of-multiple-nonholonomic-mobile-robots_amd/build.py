@@ -8,8 +8,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnmpc_hip.so")
-SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_api.cpp"]
-DEPS = SOURCES + ["nmpc_device.h", os.path.join("..", "..", "include", "nmpc.h")]
+SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_api.cpp"]
+DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h", os.path.join("..", "..", "include", "nmpc.h")]
 
 
 def _hipcc() -> str:
@@ -55,15 +55,32 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc(), "--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", "-shared",
-           '-DNMPC_SRC_HASH="%s"' % source_hash(), "-o", SO] + SOURCES
+    flags = ["--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="%s"' % source_hash()]
     if os.environ.get("NMPC_PROFILE"):
-        cmd.insert(1, "-DNMPC_PROFILE")
+        flags.append("-DNMPC_PROFILE")
     if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30
-        cmd.insert(1, "-DNMPC_POISON=" + os.environ["NMPC_POISON"])
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        flags.append("-DNMPC_POISON=" + os.environ["NMPC_POISON"])
+    only = os.environ.get("NMPC_COL_ONLY_M")   # development: instantiate the column kernel for one team size only (fast rebuilds)
+    if only:
+        flags.append("-DNMPC_COL_ONLY_M=" + only)
+    # one hipcc -c per source, in parallel (the solve kernels dominate the build time), then link
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    skip = set(filter(None, os.environ.get("NMPC_REUSE_OBJ", "").split(",")))   # development: keep the objects of unchanged sources
+
+    def cc(src):
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        if src in skip and os.path.exists(obj):
+            return obj
+        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs, cwd=CSRC)
     return SO
 
 

@@ -15,9 +15,10 @@ struct nmpc_handle {
     int32_t max_batch;
     double *ws;          // device workspace: max_batch * stride doubles
     int64_t ws_bytes;
-    int kernel;          // 2 = LDS-resident wave-per-instance kernel (default), 1 = HBM-resident workgroup kernel
+    int kernel;          // 3 = column-per-lane LDS-resident kernel (default), 2 = element-per-lane LDS-resident kernel, 1 = HBM-resident workgroup kernel
     long long *prof;     // device counters of the NMPC_PROFILE build (12 x int64), else unused
     int device;          // device the workspace lives on; made current for the duration of every call
+    bool lat_ok;         // the element-per-lane kernel's latency shapes fit the LDS for this configuration
     int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
 };
 
@@ -110,10 +111,18 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
     const char *kv = getenv("NMPC_KERNEL");
-    h->kernel = (kv && kv[0] == '1') ? 1 : 2;
+    h->kernel = (kv && kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 3;
     // horizons whose iterate does not fit the 160 KB of LDS of a CU run on the HBM-resident kernel (same algorithm, slower)
+    if (h->kernel == 3 && nmpc::col_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 2;
     if (h->kernel == 2 && nmpc::lds_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 1;
+    h->lat_ok = !(kv && kv[0] == '3') && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
     nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
+    {   // slack / dual arrays of the column kernel: pair, obstacle, control-bound (slacks + duals) and state-bound (duals) rows
+        const int64_t N = cfg->N, N1 = N + 1, m = cfg->m, NPd = m * (m - 1) / 2, MK = m * cfg->n_obs, NU = 2 * m, NXB = h->P.nxb;
+        const int64_t dual = 2 * N1 * NPd + 2 * N1 * MK + 4 * N * NU + 2 * N1 * NXB;
+        h->P.oDUAL = h->P.stride2;
+        h->P.stride2 += (dual + 15) / 16 * 16;
+    }
     int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
     h->ws_bytes = (int64_t)sizeof(double) * per * max_batch;
     if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
@@ -150,9 +159,14 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     P.order = order;
     P.order_bad = h->ord_chk + B;
     if (order && nmpc::launch_order_check(B, order, h->ord_chk, h->ord_chk + B, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
-    hipError_t e = (h->kernel == 1)
-                       ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
-                       : nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
+    // Launch shape.  The column-per-lane kernel (one wave per instance, two instances per SIMD up to six robots) is the
+    // throughput path.  Batches that leave most of the chip idle are latency problems instead: there the element-per-lane kernel
+    // spreads one instance over 2-4 waves (five / six robots: B <= 512; eight / ten robots: B <= 512), measured faster per solve.
+    int kern = h->kernel;
+    if (kern == 3 && h->lat_ok && B <= 512 && h->cfg.m >= 5) kern = 2;
+    hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
+                   : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)
+                                 : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

@@ -22,6 +22,7 @@ struct KParams {
     const int32_t *order_bad;   // device flag written by the permutation check of that order: non-zero -> the hint is ignored
     int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
     int64_t oPACK, oKT;
+    int64_t oDUAL;        // column kernel: slacks and duals of the inequality rows (touched by the stage-parallel phases only) live here, not in LDS
     int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;
 };
 
@@ -30,6 +31,9 @@ hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const d
 hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                             int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
 size_t lds_kernel_bytes(const KParams &P, int m);
+hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
+size_t col_kernel_bytes(const KParams &P, int m);
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st);

@@ -1,41 +1,49 @@
-// nmpc_solve_lds.hip — latency-oriented gfx950 solve kernel (the hot kernel).
+// nmpc_solve_col.hip — column-per-lane, register-resident Riccati stage (gfx950).  The hot kernel of the throughput path.
 //
-// A launch takes as long as "start of the longest instance + its length", so this kernel minimises the latency of ONE
-// interior-point iteration of ONE instance:
-//   * one wavefront (64 lanes) per swarm instance up to six robots (2 / 4 waves for 8 / 10 robots, and for small batches) —
-//     every "barrier" of a single-wave instance is a wave-local LDS fence;
-//   * the iterate (X, U, lambda, pair / obstacle slacks and duals, control-bound slacks and duals, state-bound duals, sin/cos
-//     cache) lives in LDS for the entire solve; the step and the adjoint residuals overlay the Riccati working set;
-//   * everything of a stage that does not depend on the cost-to-go (gradients, barrier Hessian terms, the 3x2 Jacobian entries
-//     T cos, T sin, -T v sin, T v cos per robot) is computed for all stages in parallel ("stage packs", written to HBM/L2 and
-//     prefetched one stage ahead);
-//   * one Riccati stage = assemble the augmented symmetric matrix
-//         [ Quu Qux | qu ]      = [B A]^T P [B A] + H     (upper triangle + rhs column)
+// Same interior-point algorithm, same phases and the same stage packs / stage factors as nmpc_solve_lds.hip (see there and
+// DESIGN.md 4); what differs is how one Riccati stage is executed.  There, the augmented symmetric matrix
+//         [ Quu Qux | qu ]      = [B A]^T P [B A] + H
 //         [ Qxu Qxx | qx ]
-//     directly from P with the robot-sparse A, B (<= 3 terms per index), held in REGISTERS, one static set of elements per
-//     lane (per-lane offset tables rebuilt at the start of every sweep); NU pivot steps of symmetric elimination publish one
-//     pivot row per step through LDS; what remains in the registers is [P_k | p_k].  No feedback gains are formed: the pivot
-//     rows and reciprocal pivots stream to HBM/L2 and the forward sweep does one triangular solve per stage with v_readlane;
-//   * every wave reduction ends in v_readfirstlane (uniform_f64): the control decisions of the solve are scalar branches;
-//   * multipliers: stage-parallel residual pass + robot-local adjoint recursion in registers;
-//   * a stall (5 steps below 1e-10) restarts the barrier iteration from the interior-pushed current point, at most 3 times.
-//
-// Reference blocks replaced: see nmpc_kernels.hip (same algorithm, same constants as the oracle).
+// is spread element-per-lane and every pivot step goes through LDS twice (publish the pivot row, gather two factors per
+// element).  Here ONE LANE OWNS ONE COLUMN and keeps all of its rows in registers (m[r], r = 0..NZ-1, plus the right-hand side
+// as row NZ), state column s on lane s, control column a on lane 32 + a, so that a whole stage needs no LDS traffic for the
+// matrix at all:
+//   * P_k+1 is simply what the previous stage left in rows NU.. of the state lanes; P c_k is NX FMAs with broadcast defects;
+//   * G = P [B A] is a lane gather of at most two foreign columns per lane (ds_bpermute, <= 3 terms per column) and
+//     [B A]^T G is a ROW operation, i.e. a handful of in-lane FMAs with wave-uniform coefficients per robot;
+//   * the Hessian additions arrive through per-lane LDS offsets into the staged pack (fixed per sweep);
+//   * a pivot step is  m[a] -= M[j][a] * (m[j] / d_j)  for all remaining rows a: the multiplier M[j][a] sits in lane L(a) of
+//     register m[j] and is fetched with v_readlane into an SGPR pair (symmetry), so the update is one v_fma_f64 per row with a
+//     scalar operand — no LDS round trip, no wave synchronisation, all 64 lanes of the FMA useful work on full storage;
+//   * pivot rows and reciprocal pivots stream to HBM/L2 in the layout the forward sweep of nmpc_solve_lds.hip reads.
+// One wavefront per swarm instance for every team size (ten robots: 50 of 64 lanes, 51 rows = 102 VGPRs).
 #include "nmpc_solve_common.h"
 
 namespace nmpc {
 
-template <int M_, int THB, int TPB>
-__global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
-                                                         double *__restrict__ w_out, double *__restrict__ obj_out,
-                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
-                                                         double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
+__device__ __forceinline__ double lane_read(double v, int lane)      // uniform result (SGPR pair)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// lane that owns column c of the augmented matrix: state column NU + s on lane s, control column a on lane 32 + a
+#define LC(c) (((c) < NU) ? 32 + (c) : (c) - NU)
+
+__device__ __forceinline__ double lane_gather(int src4, double v)     // v of lane src4 / 4
+{
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
+}
+
+template <int M_, int THB>
+__global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
+                                                        double *__restrict__ w_out, double *__restrict__ obj_out,
+                                                        int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
+                                                        double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
 {
     using G = G2<M_, THB>;
-    constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB, NT = G::NT;
-    constexpr int NTP = (NT + TPB - 1) / TPB;
-    constexpr int HG = (TPB / NZ) > 0 ? (TPB / NZ) : 1;   // row groups of the G pass (thread -> column, rows strided)
+    constexpr int TPB = 64;
+    constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
+    static_assert(NX <= 32 && NU <= 32, "state columns live on lanes 0..31, control columns on lanes 32..63");
     const int tid = threadIdx.x;
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
@@ -43,11 +51,25 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     const bool prs = P.pairs != 0;                 // pair rows present (the no-pair multi-robot NLP keeps NP slots that are never touched)
     const int NPA = prs ? G::NP : 0;
 
+    // LDS holds what the serial sweeps touch (states, controls, multipliers, trig cache, step) plus one scratch region; the
+    // slacks and duals of the inequality rows are only ever visited by the stage-parallel phases (coalesced, each lane its own
+    // items) and live in the instance's workspace in HBM/L2 — that is what lets two instances share a SIMD (<= 20 KB of LDS each)
     extern __shared__ double sm[];
     double *X = sm;                       // [N1*NX]
     double *U = X + N1 * NX;              // [N*NU]
     double *LAM = U + N * NU;             // [N1*NX]   lam[k] pairs with defect c_{k-1}
-    double *SPp = LAM + N1 * NX;          // [N1*NP]   pair slacks
+    double *SN = LAM + N1 * NX;           // [N*M]
+    double *CS = SN + N * M_;             // [N*M]
+    double *DX = CS + N * M_;             // [N1*NX]   step
+    double *DU = DX + N1 * NX;            // [N*NU]
+    double *RV = DU + N * NU;             // one region, three lives: PK [PACK] the staged pack of the backward sweep, FS [KTS] the staged
+    double *FS = RV, *PK = RV;            // stage factor of the forward sweep, RV [N1*NX] the residuals / QP multipliers of the adjoint recursion
+    constexpr int RG0 = G::KTS > G::PACK ? G::KTS : G::PACK;
+    double *XS = RV + ((N1 * NX > RG0) ? N1 * NX : RG0);   // [NX]
+    double *RED = XS + NX;                // [8]
+    double *BR = RED + 8;                 // [2][64]  pivot row of the current / previous pivot step, one entry per lane (multiplier broadcast)
+    double *gd = ws + inst * P.stride2 + P.oDUAL;
+    double *SPp = gd;                     // [N1*NP]   pair slacks
     double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
     double *SO = ZPp + N1 * NP;           // [N1*MK]   obstacle slacks
     double *ZO = SO + N1 * MK;            // [N1*MK]
@@ -55,30 +77,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     double *ZUU = ZUL + N * NU;           // [N*NU]
     double *ZXL = ZUU + N * NU;           // [N1*NXB]
     double *ZXU = ZXL + N1 * NXB;         // [N1*NXB]
-    double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds: s = u - lb computed on the fly
-    double *SUU = SUL + N * NU;           // [N*NU]    loses all relative accuracy once s ~ 1e-12 (active bound at mu = 1e-9)
-    double *SN = SUU + N * NU;            // [N*M]      (state-bound slacks are implicit: s = x + b, b - x; |x| <= 10 keeps them O(1) accurate)
-    double *CS = SN + N * M_;             // [N*M]
-    double *Pf = CS + N * M_;             // [NX*NX]   cost-to-go Hessian P (full symmetric storage)
-    double *PV = Pf + NX * NX;            // [NX]      cost-to-go gradient p
-    double *Gb = PV + NX;                 // [NX*LDG]  P [B A] and, in column NZ, p + P b
-    double *UR = Gb + NX * G::LDG;        // [NU*LD]   published pivot rows
-    double *INV = UR + NU * LD;           // [NU]      reciprocal pivots (contiguous with UR: streamed out together)
-    double *PK = INV + NU;                // [PACK]    current stage pack
-    double *D0 = PK + G::PACK;            // [NU]      pivots as assembled
-    double *XS = D0 + NU;                 // [NX]
-    double *RED = XS + NX;                // [8]
-    // Overlays.  W1 = [Pf | PV | Gb] and W2 = [UR | INV | PK] are only live during the Riccati sweep; the step (DX, DU) is
-    // produced after it and consumed before the next one, so it lives in W1 when it fits; the stage residuals RV of the
-    // adjoint recursion and the forward-sweep staging of the factors live in W2.
-    constexpr int W1S = NX * NX + NX + NX * G::LDG, W2S = NU * LD + NU + G::PACK;
-    double *extra = RED + 8;
-    const bool ovA = N1 * NX + N * NU <= W1S, ovB = N1 * NX <= W2S;
-    double *DX = ovA ? Pf : extra;        // [N1*NX]
-    double *DU = DX + N1 * NX;            // [N*NU]
-    if (!ovA) extra += N1 * NX + N * NU;
-    double *RV = ovB ? UR : extra;        // [N1*NX]   stage residuals / QP multipliers of the adjoint recursion (ACT follows, see below)
-    double *FS = UR;                      // forward-sweep staging of one stage factor ([UR rows | INV], KTS doubles <= W2S)
+    double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds
+    double *SUU = SUL + N * NU;           // [N*NU]
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
@@ -95,51 +95,17 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     auto bst = [&](int s) { return THB ? s : 3 * (s >> 1) + (s & 1); };            // bounded-state slot -> state index
     auto bvl = [&](int s) { return (THB && (s % 3 == 2)) ? P.thmax : P.xymax; };
 
-    // ---- static element ownership of the augmented matrix: e -> (row a, col c), c == NZ is the rhs column.
-    // Everything an element needs per stage is an LDS offset fixed for the whole solve (branch-free assembly):
-    //   value = sum_t CF[a][t] * G[ix(a,t)][c] + PK[hoff] + dl * delta
-    auto term_ix = [&](int a, int t) -> int {     // state index of term t of row/column a of [B A]
-        if (a < NU) { int i = a >> 1; return (a & 1) ? 3 * i + 2 : ((t == 1) ? 3 * i + 1 : 3 * i); }
-        int s = a - NU, i = s / 3, d = s - 3 * i;
-        return (d < 2) ? s : ((t == 0) ? s : (t == 1 ? 3 * i : 3 * i + 1));
-    };
-    // Static element ownership e -> (row a, col c) is decoded once and parked in LDS as 16-bit (a | c << 8) words; the
-    // per-element offset tables are rebuilt from it at the start of every sweep, so they only occupy registers while
-    // a sweep runs (kept for the whole kernel they cost ~100 VGPRs in every other phase and pushed the kernel into scratch).
-    const int oUR = (int)(UR - sm) * 8, oGb = (int)(Gb - sm) * 8, oPK = (int)(PK - sm) * 8, oPf = (int)(Pf - sm) * 8;
-    unsigned short *ACT = reinterpret_cast<unsigned short *>(extra + ((ovB ? 0 : N1 * NX)));    // [NTP*TPB]
-#ifdef NMPC_POISON
-    {   // debug build: every LDS word and the instance's HBM workspace start as NMPC_POISON, so that a read of anything this
-        // solve did not write shows up as a parity failure instead of depending on what ran on the CU before
-        const int nl = (int)(reinterpret_cast<double *>(ACT) - sm) + (NTP * TPB * 2 + 7) / 8;
-        for (int e = tid; e < nl; e += TPB) sm[e] = NMPC_POISON;
-        for (int e = tid; e < P.stride2; e += TPB) ws[inst * P.stride2 + e] = NMPC_POISON;
-        __syncthreads();
-    }
-#endif
-#pragma unroll
-    for (int t = 0; t < NTP; t++) {
-        int e = tid + t * TPB, a = 0;
-        unsigned short w = 0xFFFF;
-        if (e < NT) {
-            while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; }
-            w = (unsigned short)(a | ((a + e) << 8));          // e in [0, NZ-a]: columns a..NZ
-        }
-        ACT[t * TPB + tid] = w;
-    }
-    __syncthreads();
-    // the strictly lower part of the pivot-row buffer stays zero for the whole solve: the branch-free rank-1 update
-    // multiplies by UR[j][a], which must vanish for rows a < j that are already eliminated
-    for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
-    // G pass: lane -> column gcol of [B A], rows grow0, grow0 + HG, ...
-    const int gcol = tid % NZ, grow0 = tid / NZ;
-    const bool gact = tid < HG * NZ;
-    const int gx0 = term_ix(gcol, 0), gx1 = term_ix(gcol, 1), gx2 = term_ix(gcol, 2);
-    constexpr int GRPT = (NX + HG - 1) / HG;                                   // rows per thread in the G pass
-    constexpr int PBP = (64 / NX >= 3) ? 3 : (64 / NX >= 2 ? 2 : 1), PBC = (NX + PBP - 1) / PBP;   // parts / columns per part of the P b product
-    static_assert(PBP * PBC == NX, "P b split must be exact");
-    const int gpb0 = oPf + 8 * (grow0 * NX + gx0), gpb1 = oPf + 8 * (grow0 * NX + gx1), gpb2 = oPf + 8 * (grow0 * NX + gx2);
-    const int gwb = oGb + 8 * (grow0 * G::LDG + gcol);
+    // ---- column ownership: lane -> column of the augmented matrix (controls 0..NU-1, states NU..NZ-1)
+    const bool is_state = tid < NX, is_ctrl = tid >= 32 && tid < 32 + NU, lvalid = is_state || is_ctrl;
+    const int ms = is_state ? tid : 0;                       // my state index
+    const int ma = is_ctrl ? tid - 32 : 0;                   // my control index
+    const int mycol = is_state ? NU + ms : ma;               // 0 on unused lanes (they carry zero coefficients)
+    const int mrob = is_state ? ms / 3 : ma >> 1;
+    // gather sources of G = P [B A]: at most two foreign columns per lane
+    //   x_i, y_i: none;  theta_i: x_i, y_i;  v_i: x_i, y_i;  omega_i: theta_i
+    const bool th_lane = is_state && (ms - 3 * mrob == 2);
+    const int srcA = 4 * (th_lane ? 3 * mrob : (is_ctrl ? ((ma & 1) ? 3 * mrob + 2 : 3 * mrob) : tid));
+    const int srcB = 4 * (th_lane ? 3 * mrob + 1 : (is_ctrl ? ((ma & 1) ? 3 * mrob + 2 : 3 * mrob + 1) : tid));
 
     // ---- load start, pin X_0, push into the interior of the simple bounds (IPOPT bound_push)
     const double bp = 1e-2;
@@ -532,185 +498,131 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         __syncthreads();
         PROF_T(2);
 
-        // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC)
+        // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC), column-per-lane
         // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
         double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
         int ntry = 0;
         bool ok;
         for (;;) {
             ok = true;
-            // terminal cost-to-go P_N = diag(hd_N), p_N = g_N
+            // ---- per-lane byte offsets (into the staged pack) of the Hessian addition of element (row a, my column); rebuilt
+            //      per sweep so that they only occupy registers while a sweep runs
+            int hoff[NZ];
+            static_for<0, NZ>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
+                constexpr bool au = a < NU;
+                constexpr int sa = au ? 0 : a - NU, ia = au ? (a >> 1) : sa / 3, da = sa - 3 * (sa / 3);
+                int h = G::PK_ZERO;
+                if constexpr (!au && da < 2) {       // x / y row: pair blocks (negated in the pack) and the xy term of the own robot
+                    const int dc = ms - 3 * mrob;
+                    const int lo = ia < mrob ? ia : mrob, hi = ia < mrob ? mrob : ia;
+                    const int pe = G::PK_E + 3 * (lo * (2 * M_ - lo - 1) / 2 + (hi - lo - 1)) + da + dc;
+                    h = (is_state && dc < 2) ? ((ia == mrob) ? G::PK_HXY + ia : pe) : h;
+                }
+                if constexpr (au && (a & 1) == 0) h = (is_state && ms == 3 * ia + 2) ? G::PK_HVT + ia : h;       // (v_i, theta_i)
+                if constexpr (!au && da == 2) h = (is_ctrl && ma == 2 * ia) ? G::PK_HVT + ia : h;               // (theta_i, v_i)
+                h = (lvalid && mycol == a) ? G::PK_HD + a : h;
+                hoff[a] = 8 * (lvalid ? h : G::PK_ZERO);
+            });
+            const int goff = 8 * (lvalid ? G::PK_G + mycol : G::PK_ZERO), cfo = 8 * (G::PK_CF + 3 * mycol);
+            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N: rows NU.. of the state lanes
+            double m[NZ + 1];
             {
                 const double *pkN = gpack + (size_t)N * G::PACK;
-                for (int e = tid; e < NX * NX; e += TPB) {
-                    int r = e / NX, c = e - r * NX;
-                    Pf[e] = (r == c) ? pkN[G::PK_HD + NU + r] : 0.0;
-                }
-                for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
+                const double hdN = is_state ? pkN[G::PK_HD + NU + ms] : 0.0, gN = is_state ? pkN[G::PK_G + NU + ms] : 0.0;
+                static_for<0, NU>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
+                static_for<0, NX>([&](auto rc) { constexpr int r = decltype(rc)::value; m[NU + r] = (is_state && ms == r) ? hdN : 0.0; });
+                m[NZ] = gN;
             }
-            // ---- per-element LDS byte offsets (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries,
-            //      the coefficient triple and the Hessian addition of the assembly; the mirror positions of the Schur block
-            int ea[NTP], uoa[NTP], uoc[NTP], pg0[NTP], pg1[NTP], pg2[NTP], pca[NTP], pho[NTP], wa1[NTP], wa2[NTP];
-            double dl[NTP];
-        #pragma unroll
-            for (int t = 0; t < NTP; t++) {
-                // branch-free decode (selects only): this runs at the start of every sweep
-                const int w = ACT[t * TPB + tid];
-                const bool valid = w != 0xFFFF;
-                const int a = valid ? (w & 0xFF) : 0, c = valid ? (w >> 8) : 0;
-                const bool au = a < NU, odd = (a & 1) != 0, rhs = c == NZ;
-                const int iu = a >> 1;                                          // robot of a control row
-                const int sa = au ? 0 : a - NU, sc = (c < NU || rhs) ? 0 : c - NU;   // state indices of row / column (0 when not a state)
-                const int ia = sa / 3, da = sa - 3 * ia, ic = sc / 3, dc = sc - 3 * ic;
-                // state index of term t of row/column a of [B A] (term_ix)
-                const int ix0 = au ? (odd ? 3 * iu + 2 : 3 * iu) : sa;
-                const int ix1 = au ? (odd ? 3 * iu + 2 : 3 * iu + 1) : (da < 2 ? sa : 3 * ia);
-                const int ix2 = au ? (odd ? 3 * iu + 2 : 3 * iu) : (da < 2 ? sa : 3 * ia + 1);
-                ea[t] = valid ? a : -1;
-                uoa[t] = oUR + 8 * a; uoc[t] = oUR + 8 * c;
-                pg0[t] = oGb + 8 * (ix0 * G::LDG + c); pg1[t] = oGb + 8 * (ix1 * G::LDG + c); pg2[t] = oGb + 8 * (ix2 * G::LDG + c);
-                pca[t] = oPK + 8 * (G::PK_CF + 3 * a);
-                dl[t] = (valid && c == a && au) ? 1.0 : 0.0;      // the inertia shift delta acts on the control diagonal only
-                // Hessian addition: lowest priority first, later selects override
-                int h = G::PK_ZERO;
-                h = (!au && !rhs && c >= NU && da < 2 && dc < 2) ? ((ia == ic) ? (G::PK_HXY + ia) : (G::PK_E + 3 * pidx<M_>(ia, ic) + da + dc)) : h;
-                h = (au && !odd && c == NU + 3 * iu + 2) ? (G::PK_HVT + iu) : h;
-                h = (c == a) ? (G::PK_HD + a) : h;
-                h = rhs ? (G::PK_G + a) : h;
-                pho[t] = oPK + 8 * (valid ? h : G::PK_ZERO);
-                // mirror positions of the Schur block [P | p] (state rows only; PV follows Pf)
-                const int w1 = au ? 0 : (rhs ? NX * NX + sa : sa * NX + sc), w2 = au ? 0 : (rhs ? NX * NX + sa : sc * NX + sa);
-                wa1[t] = oPf + 8 * w1; wa2[t] = oPf + 8 * w2;
-            }
-            // the pivot-row area doubles as staging / residual storage between sweeps: restore the zero lower part the
-            // select-free rank-1 update relies on
-            for (int e = tid; e < NU * LD; e += TPB) UR[e] = 0.0;
             // prefetch pack N-1 into registers
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
             double pkr[PKR];
 #pragma unroll
             for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
-            lds_sync<TPB>();
             for (int k = N - 1; k >= 0; k--) {
-                // ---- stage pack -> LDS; prefetch the next one
+                // ---- stage pack -> LDS (the inertia shift delta joins the control diagonal here); prefetch the next one
+                lds_sync<TPB>();         // every read of the previous stage's pack is done
 #pragma unroll
-                for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; if (e < G::PACK) PK[e] = pkr[t]; }
+                for (int t = 0; t < PKR; t++) {
+                    int e = tid + t * TPB;
+                    if (e < G::PACK) PK[e] = (e >= G::PK_HD && e < G::PK_HD + NU) ? pkr[t] + delta : pkr[t];
+                }
                 if (k > 0) {
 #pragma unroll
                     for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
                 }
                 lds_sync<TPB>();
-                // ---- G = P [B A] (<= 3 terms per column, thread = column, rows strided) and its last column p + P b, b = -c_k
-                if (gact) {
-                    const double c0 = PK[G::PK_CF + 3 * gcol], c1 = PK[G::PK_CF + 3 * gcol + 1], c2 = PK[G::PK_CF + 3 * gcol + 2];
-                    double p0[GRPT], p1[GRPT], p2[GRPT];          // all reads first (one LDS latency instead of GRPT)
-                    static_for<0, GRPT>([&](auto nc) {
-                        constexpr int n = decltype(nc)::value;
-                        p0[n] = lds_ld(sm, gpb0, 8 * n * HG * NX); p1[n] = lds_ld(sm, gpb1, 8 * n * HG * NX); p2[n] = lds_ld(sm, gpb2, 8 * n * HG * NX);
-                    });
-                    static_for<0, GRPT>([&](auto nc) {
-                        constexpr int n = decltype(nc)::value;
-                        if ((NX % HG == 0) || grow0 + n * HG < NX) lds_st(sm, gwb, 8 * n * HG * G::LDG, c0 * p0[n] + c1 * p1[n] + c2 * p2[n]);
-                    });
+                // coefficients of the <= 3 terms of my column of [B A]: own, gathered A, gathered B
+                double kO, kA, kB;
+                {
+                    const double c0 = lds_ld(PK, cfo, 0), c1 = lds_ld(PK, cfo, 8), c2 = lds_ld(PK, cfo, 16);
+                    kO = is_state ? c0 : 0.0; kA = is_state ? c1 : (is_ctrl ? c0 : 0.0); kB = is_state ? c2 : (is_ctrl ? c1 : 0.0);
                 }
-                // last column p + P b (b = -c_k): the NX dot products are split into PBP column parts over PBP * NX lanes of the
-                // first wave and recombined with two lane shuffles (was: NX lanes doing NX serial LDS reads each)
-                if (tid < 64) {
-                    const int pr_ = tid % NX, part = tid / NX;
-                    double a = 0.0;
-                    if (part < PBP) {
-                        const int pb = oPf + 8 * (pr_ * NX + part * PBC), cb = oPK + 8 * (G::PK_C + part * PBC);
-                        double pq[PBC], cq[PBC];
-#pragma unroll
-                        for (int c = 0; c < PBC; c++) { pq[c] = lds_ld(sm, pb, 8 * c); cq[c] = lds_ld(sm, cb, 8 * c); }
-#pragma unroll
-                        for (int c = 0; c < PBC; c++) a = fma(-pq[c], cq[c], a);
-                    }
-                    double ssum = a;
-                    if constexpr (PBP >= 2) ssum += __shfl(a, tid + NX);
-                    if constexpr (PBP >= 3) ssum += __shfl(a, tid + 2 * NX);
-                    if (tid < NX) Gb[tid * G::LDG + NZ] = PV[tid] + ssum;
+                // ---- 1. right-hand side p + P b, b = -c_k (defects broadcast from the pack)
+                static_for<0, NX>([&](auto sc) { constexpr int s = decltype(sc)::value; m[NZ] = fma(-m[NU + s], PK[G::PK_C + s], m[NZ]); });
+                // ---- 2. G = P [B A] (and the same combination of the right-hand side): own column + two gathered columns
+                {
+                    double tA[NX + 1], tB[NX + 1];      // all gathers first (one LDS-crossbar latency for the stage, not one per row)
+                    static_for<0, NX + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q] = lane_gather(srcA, m[NU + q]); tB[q] = lane_gather(srcB, m[NU + q]); });
+                    static_for<0, NX + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NU + q] = fma(kB, tB[q], fma(kA, tA[q], kO * m[NU + q])); });
                 }
-                lds_sync<TPB>();
                 PROF_T(9);
-                // ---- my elements of [B A]^T G + H (and the rhs column), branch-free, into registers
-                double mv[NTP], d0r[NTP];      // d0r: values as assembled (the owners of the control diagonals test their pivot against it)
-                // reads first, in batches of AB elements (one LDS latency per batch instead of one per element; the batch size
-                // bounds the registers held by in-flight loads)
-                constexpr int AB = 4;
-                static_for<0, (NTP + AB - 1) / AB>([&](auto bc) {
-                    constexpr int b0 = decltype(bc)::value * AB, b1 = (b0 + AB < NTP) ? b0 + AB : NTP;
-                    double q0[AB], q1[AB], q2[AB], r0[AB], r1[AB], r2[AB], hh[AB];
-#pragma unroll
-                    for (int t = b0; t < b1; t++) {
-                        q0[t - b0] = lds_ld(sm, pca[t], 0); q1[t - b0] = lds_ld(sm, pca[t], 8); q2[t - b0] = lds_ld(sm, pca[t], 16);
-                        r0[t - b0] = lds_ld(sm, pg0[t], 0); r1[t - b0] = lds_ld(sm, pg1[t], 0); r2[t - b0] = lds_ld(sm, pg2[t], 0);
-                        hh[t - b0] = lds_ld(sm, pho[t], 0);
-                    }
-#pragma unroll
-                    for (int t = b0; t < b1; t++) {
-                        double v = q0[t - b0] * r0[t - b0] + q1[t - b0] * r1[t - b0] + q2[t - b0] * r2[t - b0];
-                        v += hh[t - b0] + dl[t] * delta;
-                        mv[t] = v;
-                        d0r[t] = v;
-                    }
+                // ---- 3. [B A]^T G: a row operation, i.e. in-lane, with the wave-uniform coefficients of each robot
+                static_for<0, M_>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const double Tc = PK[G::PK_CF + 3 * (2 * i)], Ts = PK[G::PK_CF + 3 * (2 * i) + 1], Tt = PK[G::PK_CF + 3 * (2 * i + 1)];
+                    const double ai = PK[G::PK_CF + 3 * (NU + 3 * i + 2) + 1], bi = PK[G::PK_CF + 3 * (NU + 3 * i + 2) + 2];
+                    const double gx = m[NU + 3 * i], gy = m[NU + 3 * i + 1], gt = m[NU + 3 * i + 2];
+                    m[2 * i] = fma(Ts, gy, Tc * gx);
+                    m[2 * i + 1] = Tt * gt;
+                    m[NU + 3 * i + 2] = fma(bi, gy, fma(ai, gx, gt));
                 });
+                // ---- 4. Hessian additions and gradient
+                static_for<0, NZ>([&](auto rc) { constexpr int r = decltype(rc)::value; m[r] += lds_ld(PK, hoff[r], 0); });
+                m[NZ] += lds_ld(PK, goff, 0);
                 PROF_T(10);
-                // ---- NU pivot steps of symmetric elimination; pivot rows are published through LDS
-                // pivot test + reciprocal of pivot j: evaluated by every thread on its own slice element, meaningful on the owner
-                // of (j,j); < 0 flags a non-positive pivot.  It is computed right after the slice holding (j,j) got its last
-                // update, so its latency hides under the rank-1 updates of the other slices.
+                // ---- 5. NU pivot steps.  Row a loses M[j][a] / d_j times the pivot row; M[j][a] is lane L(a) of m[j] (symmetry): the
+                //      pivot row goes to LDS once (one entry per lane) and every lane reads the multipliers of all remaining rows back
+                //      as broadcasts (uniform addresses, two rows per ds_read_b128), so the updates are plain VGPR FMAs
+                double d0s[NU];                          // the control diagonals as assembled (pivot test reference), wave-uniform
+                static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; d0s[j] = lane_read(m[j], LC(j)); });
                 auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0) && d > 0.0) ? rcp_nr(d) : -1.0; };
-                double inv_own = pivot_inv(mv[G::diag_e(0) / TPB], d0r[G::diag_e(0) / TPB]);
+                double inv_cur = pivot_inv(d0s[0], d0s[0]);
+                double invv = 0.0, rhsv = 0.0;           // lane j <- reciprocal pivot j, right-hand side of pivot row j
                 static_for<0, NU>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    constexpr int td = G::diag_e(j) / TPB;
                     if (ok) {
-                        // publish pivot row j (only the at most two slices that hold it) and its reciprocal pivot
-                        static_for<0, NTP>([&](auto tc) {
-                            constexpr int t = decltype(tc)::value;
-                            if constexpr (G::slice_lo(t, TPB) <= j && j <= G::slice_hi(t, TPB)) { if (ea[t] == j) lds_st(sm, uoc[t], 8 * j * LD, mv[t]); }
-                        });
-                        if (ea[td] == j && dl[td] != 0.0) INV[j] = inv_own;
-                        lds_sync<TPB>();
-                        const double inv = uniform_f64(INV[j]);
+                        const double inv = inv_cur;
                         if (!(inv > 0.0)) ok = false;
                         else {
-                            // rank-1 update of every live slice, branch-free and select-free: for rows a <= j the factor
-                            // UR[j][a] is 0 (a < j) or annihilates the already published pivot row itself (a == j)
-                            if constexpr (j + 1 < NU) {
-                                constexpr int tn = G::diag_e(j + 1) / TPB;       // slice of the next pivot: update it first
-                                mv[tn] = fma(-(lds_ld(sm, uoa[tn], 8 * j * LD) * inv), lds_ld(sm, uoc[tn], 8 * j * LD), mv[tn]);
-                                inv_own = pivot_inv(mv[tn], d0r[tn]);
-                                static_for<0, NTP>([&](auto tc) {
-                                    constexpr int t = decltype(tc)::value;
-                                    if constexpr (G::slice_hi(t, TPB) > j && t != tn)
-                                        mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
-                                });
-                            } else {
-                                static_for<0, NTP>([&](auto tc) {
-                                    constexpr int t = decltype(tc)::value;
-                                    if constexpr (G::slice_hi(t, TPB) > j)
-                                        mv[t] = fma(-(lds_ld(sm, uoa[t], 8 * j * LD) * inv), lds_ld(sm, uoc[t], 8 * j * LD), mv[t]);
-                                });
+                            double *br = BR + (j & 1) * 64;
+                            br[tid] = m[j];
+                            if (lvalid) gkt[(size_t)k * G::KTS + j * LD + mycol] = m[j];      // pivot row j as the forward sweep reads it
+                            const double rhs_j = lane_read(m[NZ], LC(j));
+                            invv = (tid == j) ? inv : invv; rhsv = (tid == j) ? rhs_j : rhsv;
+                            const double rjv = m[j] * inv;
+                            lds_sync<TPB>();
+                            double sm_[NZ];                  // multipliers of the remaining rows (wave-uniform values in VGPRs)
+                            static_for<j + 1, NZ>([&](auto ac) { constexpr int a = decltype(ac)::value; sm_[a] = br[LC(a)]; });
+                            if constexpr (j + 1 < NU) {       // the next pivot row first: its reciprocal overlaps the other rows
+                                m[j + 1] = fma(-sm_[j + 1], rjv, m[j + 1]);
+                                inv_cur = pivot_inv(lane_read(m[j + 1], LC(j + 1)), d0s[j + 1]);
                             }
+                            static_for<(j + 1 < NU ? j + 2 : j + 1), NZ>([&](auto ac) {
+                                constexpr int a = decltype(ac)::value;
+                                m[a] = fma(-sm_[a], rjv, m[a]);
+                            });
+                            m[NZ] = fma(-rhs_j, rjv, m[NZ]);
                         }
                     }
                 });
                 PROF_T(11);
                 if (!ok) break;
-                // ---- what is left is [P_k | p_k]: back to LDS (both triangles)
-                if (k >= 1) {
-#pragma unroll
-                    for (int t = 0; t < NTP; t++) if (ea[t] >= NU) { lds_st(sm, wa1[t], 0, mv[t]); lds_st(sm, wa2[t], 0, mv[t]); }
-                }
-                lds_sync<TPB>();
-                // ---- stream the pivot rows and reciprocal pivots of this stage to HBM/L2 (coalesced).  No feedback gains are
-                //      formed: the forward sweep needs K dx + k for ONE dx only, i.e. one triangular solve per stage.
-                for (int e = tid; e < NU * LD + NU; e += TPB) gkt[(size_t)k * G::KTS + e] = UR[e];
+                // reciprocal pivots and the right-hand sides of the pivot rows (lanes 0..NU-1 hold them)
+                if (tid < NU) { gkt[(size_t)k * G::KTS + NU * LD + tid] = invv; gkt[(size_t)k * G::KTS + tid * LD + NZ] = rhsv; }
+                // what is left in rows NU.. of the state lanes is [P_k | p_k]
             }
             if (ok) break;
-            __syncthreads();
             ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
@@ -1045,102 +957,68 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 #endif
 }
 
-// LDS bytes of one instance
-template <int M_, int THB> static size_t lds_bytes(const KParams &P, int tpb)
+// LDS bytes of one instance of the column-per-lane kernel
+template <int M_, int THB> static size_t col_lds_bytes(const KParams &P)
 {
     using G = G2<M_, THB>;
     const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
-    const size_t W1S = (size_t)G::NX * G::NX + G::NX + (size_t)G::NX * G::LDG, W2S = (size_t)G::NU * G::LD + G::NU + G::PACK;
-    size_t d = N1 * G::NX * 2 + N * G::NU * 5 + N1 * G::NP * 2 + N1 * MK * 2 + N1 * G::NXB * 2 + N * M_ * 2 + W1S + W2S + G::NU + G::NX + 8;
-    if (N1 * G::NX + N * G::NU > W1S) d += N1 * G::NX + N * G::NU;      // step does not fit the Riccati working area
-    if (N1 * G::NX > W2S) d += N1 * G::NX;
-    d += ((size_t)((G::NT + tpb - 1) / tpb) * tpb * 2 + 7) / 8;      // 16-bit element table
+    size_t d = N1 * G::NX * 3 + N * G::NU * 2 + N * M_ * 2;
+    (void)MK;
+    const size_t rg0 = G::KTS > G::PACK ? G::KTS : G::PACK;
+    d += (N1 * G::NX > rg0) ? N1 * G::NX : rg0;
+    d += G::NX + 8 + 128;
     return d * sizeof(double);
 }
 
-template <int M_, int THB, int TPB> static hipError_t launch2_mtt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
-                                                                  int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
+                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
-    size_t lds = lds_bytes<M_, THB>(P, TPB);
+    size_t lds = col_lds_bytes<M_, THB>(P);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = solve_lds_kernel<M_, THB, TPB>;
+    auto kern = solve_col_kernel<M_, THB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(TPB), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
     return hipGetLastError();
 }
-
-template <int M_, int THB> static hipError_t launch2_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
-                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
-{
-    // Throughput shape: one wave per instance up to six robots (4 instances per CU, 1024 resident on the chip); the augmented
-    // matrix of 8 / 10 robots (860 / 1325 elements) is spread over 2 / 4 waves so that the per-thread element tables stay in
-    // registers (64 threads spill to scratch there).
-    // Latency shape (five and six robots): a batch that leaves most of the chip idle is solved with 2 or 4 waves per instance —
-    // measured 189 / 148 / 139 us per iteration at 64 / 128 / 256 threads (m=6, N=20, one instance per CU).  This is the
-    // reference's own use (one swarm per control period) and the tail of small closed-loop batches.
-    // (the wider shapes carry a larger 16-bit element table: a horizon that only fits the 160 KB of LDS in the throughput
-    // shape stays on it)
-    if constexpr (M_ == 5 || M_ == 6) {
-        if (B <= 256 && lds_bytes<M_, THB>(P, 256) <= (size_t)160 * 1024) return launch2_mtt<M_, THB, 256>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-        if (B <= 512 && lds_bytes<M_, THB>(P, 128) <= (size_t)160 * 1024) return launch2_mtt<M_, THB, 128>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    }
-    constexpr int TPB = (M_ <= 6) ? 64 : (M_ <= 8 ? 128 : 256);
-    return launch2_mtt<M_, THB, TPB>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-}
-template <int M_> static hipError_t launch2_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+template <int M_> static hipError_t launch3_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                                               int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
-    return P.thb ? launch2_mt<M_, 1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st)
-                 : launch2_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    return P.thb ? launch3_mt<M_, 1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st)
+                 : launch3_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
 }
 
-hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                             int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
     switch (m) {
-    case 1: return launch2_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 2: return launch2_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 3: return launch2_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 4: return launch2_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 5: return launch2_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 6: return launch2_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 8: return launch2_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 10: return launch2_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+#ifndef NMPC_COL_ONLY_M
+    case 1: return launch3_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 2: return launch3_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 3: return launch3_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 4: return launch3_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 5: return launch3_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 6: return launch3_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 8: return launch3_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 10: return launch3_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+#else
+    case NMPC_COL_ONLY_M: return launch3_m<NMPC_COL_ONLY_M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+#endif
     default: return hipErrorInvalidValue;
     }
 }
 
-// LDS bytes one instance of the LDS-resident kernel needs in its throughput shape (0 if m is not supported); the C ABI falls
-// back to the HBM-resident kernel when this exceeds the 160 KB of a CU
-size_t lds_kernel_bytes(const KParams &P, int m)
+// LDS bytes one instance of the column-per-lane kernel needs (0 if m is not supported)
+size_t col_kernel_bytes(const KParams &P, int m)
 {
-#define LB(M, T) case M: return P.thb ? lds_bytes<M, 1>(P, T) : lds_bytes<M, 0>(P, T);
+#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P) : col_lds_bytes<M, 0>(P);
     switch (m) {
-        LB(1, 64) LB(2, 64) LB(3, 64) LB(4, 64) LB(5, 64) LB(6, 64) LB(8, 128) LB(10, 256)
+        LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(8) LB(10)
     default: return 0;
     }
 #undef LB
-}
-
-// workspace doubles per instance for this kernel (packs + transposed gains)
-void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride)
-{
-    const int thb = P.thb;
-    int64_t pack = 0, kts = 0;
-#define SZ(M)                                                                                                                     \
-    case M:                                                                                                                       \
-        pack = thb ? G2<M, 1>::PACK : G2<M, 0>::PACK;                                                                             \
-        kts = thb ? G2<M, 1>::KTS : G2<M, 0>::KTS;                                                                                \
-        break;
-    switch (m) { SZ(1) SZ(2) SZ(3) SZ(4) SZ(5) SZ(6) SZ(8) SZ(10) default: break; }
-#undef SZ
-    int64_t o = 0;
-    *pack_off = o; o += (int64_t)(P.N + 1) * pack; o = (o + 15) / 16 * 16;
-    *kt_off = o; o += (int64_t)P.N * kts; o = (o + 15) / 16 * 16;
-    *stride = o;
 }
 
 }  // namespace nmpc

@@ -1,0 +1,150 @@
+// nmpc_solve_common.h — geometry, pinned-order arithmetic helpers and wave primitives shared by the LDS-resident solve kernels
+// (nmpc_solve_lds.hip: element-per-lane Riccati stage; nmpc_solve_col.hip: column-per-lane, register-resident Riccati stage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "nmpc_device.h"
+
+namespace nmpc {
+
+template <int M_, int THB> struct G2 {
+    static constexpr int NX = 3 * M_, NU = 2 * M_, NP = M_ * (M_ - 1) / 2, NZ = NX + NU, LD = NZ + 1;
+    static constexpr int NXB = M_ * (2 + THB);
+    static constexpr int NT = NZ * (NZ + 1) / 2 + NZ;   // upper triangle + rhs column
+    // stage pack layout (doubles)
+    static constexpr int PK_G = 0;                 // [NZ]  rhs gradient  (u part then x part)
+    static constexpr int PK_HD = NZ;               // [NZ]  diagonal Hessian additions (without delta)
+    static constexpr int PK_HXY = 2 * NZ;          // [M]   (x_i,y_i) entry of robot i's diagonal block
+    static constexpr int PK_HVT = 2 * NZ + M_;     // [M]   (v_i,theta_i) cross term
+    static constexpr int PK_E = 2 * NZ + 2 * M_;   // [3 NP] NEGATED pair blocks -E_ij
+    static constexpr int PK_C = PK_E + 3 * (NP > 0 ? NP : 0);   // [NX]  defects c_k
+    static constexpr int PK_CF = PK_C + NX;        // [NZ][3] coefficients of the <=3 terms of each row/column of [B A]
+    static constexpr int PK_ZERO = PK_CF + 3 * NZ; // one zero entry (target of "no Hessian addition")
+    static constexpr int PACK = ((PK_ZERO + 1 + 7) / 8) * 8;
+    static constexpr int LDG = NZ + 1;             // row stride of G = P [B A | b-part]
+    // element e of the row-major upper triangle (+ rhs column) lives in row row_of(e); thread tid owns e = tid + t*TPB, so
+    // "slice" t holds rows slice_lo(t)..slice_hi(t): compile-time knowledge of which slices a pivot step touches
+    static constexpr int row_of(int e) { int a = 0; while (e >= NZ - a + 1) { e -= NZ - a + 1; a++; } return a; }
+    static constexpr int diag_e(int j) { int e = 0; for (int a = 0; a < j; a++) e += NZ - a + 1; return e; }   // flat index of element (j,j)
+    static constexpr int slice_lo(int t, int tpb) { return row_of(t * tpb); }
+    static constexpr int slice_hi(int t, int tpb) { return row_of((t * tpb + tpb - 1 < NT) ? (t * tpb + tpb - 1) : (NT - 1)); }
+    static constexpr int KTS = (NU * LD + NU + 7) / 8 * 8;      // per stage: the NU pivot rows [Uuu | Uux | rhs] and the NU reciprocal pivots
+};
+
+// ---- single evaluation points.  Constraint values, slack steps and defects are recomputed at several places of an
+// iteration (Newton right-hand side, step-size rule, multiplier recursion, update).  With sigma = z/s up to 1e13 a
+// last-bit difference between two sites (e.g. a differently contracted a*b+c) shows up as 1e-7 in the dual residual, so
+// every site goes through these helpers, whose operation order is pinned with explicit fma().
+__device__ __forceinline__ double h_pair(double ex, double ey, double dmin2) { return fma(ex, ex, ey * ey) - dmin2; }
+__device__ __forceinline__ double ds_pair(double ex, double ey, double ddx, double ddy, double dmin2, double sv)
+{
+    return fma(2.0 * ex, ddx, (2.0 * ey) * ddy) + (h_pair(ex, ey, dmin2) - sv);
+}
+__device__ __forceinline__ double r_obs(double ex, double ey) { return sqrt(fma(ex, ex, ey * ey)); }
+__device__ __forceinline__ double h_obs(double rr, double robdim, double orad, double margin) { return rr - robdim - orad - margin; }
+__device__ __forceinline__ double ds_obs(double ex, double ey, double rr, double d0, double d1, double hv, double sv)
+{
+    return fma(ex, d0, ey * d1) / rr + (hv - sv);
+}
+__device__ __forceinline__ double defect_xy(double xn, double x, double tu, double cs) { return xn - fma(tu, cs, x); }   // tu = T*v
+__device__ __forceinline__ double defect_th(double xn, double x, double T, double w) { return xn - fma(T, w, x); }
+__device__ __forceinline__ double ds_bound(double jd, double hv, double sv) { return jd + (hv - sv); }
+__device__ __forceinline__ double dz_of(double mu, double sv, double zv, double ds) { return fma(-zv, ds, fma(-sv, zv, mu)) / sv; }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (indices usable in `if constexpr`)
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// LDS access through a per-thread byte offset fixed at kernel start plus a compile-time constant: lowers to
+// ds_read_b64 / ds_write_b64 with the constant in the instruction's offset field (no address arithmetic in the hot loops)
+__device__ __forceinline__ double lds_ld(const double *sm, int byteoff, int cbytes)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(sm) + byteoff + cbytes);
+}
+__device__ __forceinline__ void lds_st(double *sm, int byteoff, int cbytes, double v)
+{
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(sm) + byteoff + cbytes) = v;
+}
+
+// LDS-only synchronisation of the threads of one instance.  __syncthreads() also drains vmcnt, i.e. it waits for every
+// global load/store in flight — which would turn the stage-ahead prefetches of the sweeps into synchronous loads.  One
+// wave executes its LDS instructions in order, so a single-wave instance only needs the LDS counter and a compiler fence;
+// multi-wave instances add the hardware barrier.
+template <int TPB> __device__ __forceinline__ void lds_sync()
+{
+    // release/acquire fences restricted to the LDS address space ("local"): s_waitcnt lgkmcnt(0) only, vmcnt untouched
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if constexpr (TPB > 64) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// reciprocal: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, a third of the cost of an IEEE division chain)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+template <int M_> __device__ __forceinline__ int pidx(int a, int b) { return a * (2 * M_ - a - 1) / 2 + (b - a - 1); }
+
+// A value every lane of the wave holds identically (a finished reduction, an LDS word read at a wave-uniform address),
+// moved through v_readfirstlane: the compiler then KNOWS it is wave-uniform, so the branches that depend on it (line-search
+// acceptance, convergence, pivot failure, barrier update) become scalar branches instead of exec-masked divergent regions.
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int TPB> __device__ __forceinline__ double wsum(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if constexpr (TPB > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; w++) t += red[w];
+        v = t;
+    }
+    return uniform_f64(v);
+}
+template <int TPB> __device__ __forceinline__ double wmax(double v, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    if constexpr (TPB > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = red[0];
+        for (int w = 1; w < TPB / 64; w++) t = fmax(t, red[w]);
+        v = t;
+    }
+    return uniform_f64(v);
+}
+template <int TPB> __device__ __forceinline__ double wmin(double v, double *red) { return -wmax<TPB>(-v, red); }
+
+#ifdef NMPC_PROFILE
+#define PROF_T(i)                                                                                                                 \
+    do {                                                                                                                          \
+        long long _t = clock64();                                                                                                 \
+        prof[i] += _t - tlast;                                                                                                    \
+        tlast = _t;                                                                                                               \
+    } while (0)
+#else
+#define PROF_T(i) do { } while (0)
+#endif
+
+}  // namespace nmpc

@@ -18,6 +18,7 @@ from tests import helpers as Hh
 
 importlib.import_module("nmpc_amd.build").build(force=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+REPS = int(os.environ.get("PHASE_REPS", "1"))
 name = sys.argv[2] if len(sys.argv) > 2 else "six"
 ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(30)}[name]
 cfg = Hh.to_product_cfg(ocfg, max_iter=2000)
