@@ -1,0 +1,69 @@
+/*
+ * nmpc_lidar.h — C ABI of the LIDAR-ray distance-state NMPC solve (part of libnmpc_hip.so).
+ *
+ * Drop-in boundary for the per-timestep solve of
+ *   V4 = AllScripts/obs_avoid_static_first_scenario_v4.py   (and V3 = ..._v3.py: Nc = N, lw = 0)
+ * of the reference, i.e. of
+ *     solver = nlpsol('solver','ipopt', nlp_prob, opts)                     V4:156-157
+ *     sol    = solver(x0=,p=,lbx=,ubx=,lbg=,ubg=)                           V4:245
+ * for B independent robots at once.  Same conventions as nmpc.h: caller-owned DEVICE buffers (fp64 / int32, batch index
+ * leading), stream-ordered, integer return codes, per-instance status instead of errors for non-convergence; one handle must
+ * not be used from two streams or threads at once.
+ *
+ * The NLP (V4:78-151): 3 + R states per stage [x y theta d_1..d_R], controls U[:, min(k, Nc-1)] (move blocking), cost
+ * sum_k (x_k-xs)'Q(x_k-xs) + u'Ru + lw sum_m 1/d_mk^2, equality rows g = [gx; gd] with gd: d_{m,k+1} = ||p_{k+1} - pObs_m||_1 and
+ * pObs_m the lidar point seen at stage 0.  Variable bounds are an INPUT (lbx / ubx of length n_var, +-inf allowed): the script
+ * builds them as "all pose bounds, then all distance bounds" (V4:161-176), which does not line up with its own stage-major
+ * packing; the caller passes whatever the script passes and the solve honours it entry by entry.
+ */
+#ifndef NMPC_LIDAR_H_
+#define NMPC_LIDAR_H_
+
+#include "nmpc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMPC_LIDAR_MAX_RAYS 16
+
+typedef struct nmpc_lidar_config {
+    int32_t N;        /* prediction horizon (V4:59: 100; V3: 125)                                   */
+    int32_t Nc;       /* control horizon, 1..N (V4:60: 50; V3: N)                                   */
+    int32_t R;        /* numRays, 0..NMPC_LIDAR_MAX_RAYS (V4:62: 10)                                */
+    int32_t max_iter; /* 2000 (V4:156)                                                              */
+    double T;         /* 0.075                                                                      */
+    double q[3], r[2];/* Q = diag(1, 5, 0.1), R = diag(0.5, 0.05)  (V4:119-120)                     */
+    double lw;        /* weight of sum 1/d^2 (V4:121: 0.1; V3: 0)                                   */
+    double tol;       /* 1e-8 */
+    double mu_init;   /* 0.5  */
+} nmpc_lidar_config_t;
+
+typedef struct nmpc_lidar_handle nmpc_lidar_handle_t;
+
+int32_t nmpc_lidar_n_var(const nmpc_lidar_config_t *cfg); /* (3+R)(N+1) + 2 Nc   (V4:155) */
+int32_t nmpc_lidar_n_g(const nmpc_lidar_config_t *cfg);   /* (3+R)(N+1)          (V4:151,158) */
+int32_t nmpc_lidar_n_p(const nmpc_lidar_config_t *cfg);   /* 6 + 2R              (V4:101) */
+
+/* Replaces nlpsol(...) of V4:156-157.  lbx / ubx: HOST arrays of n_var entries (args['lbx'], args['ubx'] of V4:174-176). */
+int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, const double *ubx, int32_t max_batch, nmpc_lidar_handle_t **out);
+int32_t nmpc_lidar_destroy(nmpc_lidar_handle_t *h);
+
+/*
+ * Replaces sol = solver(x0=,p=,...) (V4:245) for B robots.
+ *   p [B][6+2R] = [x0; xs; scan; ray angles] (V4:230-236),  w0 / w_out [B][n_var] = [vec(X); vec(U)] (V4:239-241,247-252)
+ *   obj, status, iters, kkt [B]  (may be NULL)
+ */
+int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
+                               int32_t *status, int32_t *iters, double *kkt, void *stream);
+
+/* f (V4:135-136) and g [B][n_g] = [gx; gd] (V4:151) at w: backs sol['f'] / sol['g'] */
+int32_t nmpc_lidar_eval_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream);
+
+/* warm-start shuffle of V4:258-270: U rows drop first / repeat last; X rows [X_1..X_N; X_{N-1}] */
+int32_t nmpc_lidar_shift_batch(nmpc_lidar_handle_t *h, int32_t B, const double *w_in, double *w_next, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMPC_LIDAR_H_ */

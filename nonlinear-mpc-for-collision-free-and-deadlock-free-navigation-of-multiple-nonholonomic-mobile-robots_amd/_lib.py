@@ -15,6 +15,8 @@ STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Erro
                 3: "Infeasible_Problem_Detected", 4: "Restoration_Failed"}
 ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMPC_E_NOMEM"}
 
+LIDAR_EXPORTS = ["nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p", "nmpc_lidar_create", "nmpc_lidar_destroy", "nmpc_lidar_solve_batch",
+                 "nmpc_lidar_eval_batch", "nmpc_lidar_shift_batch"]
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_destroy",
            "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
 
@@ -27,6 +29,12 @@ class CConfig(C.Structure):
                 ("rob_dim", C.c_double), ("margin", C.c_double), ("pad_value", C.c_double),
                 ("obs", C.c_double * (3 * NMPC_MAX_OBSTACLES)), ("tol", C.c_double), ("mu_init", C.c_double),
                 ("max_iter", C.c_int32), ("pair_rows", C.c_int32)]
+
+
+class CLidarConfig(C.Structure):
+    """nmpc_lidar_config_t (include/nmpc_lidar.h)"""
+    _fields_ = [("N", C.c_int32), ("Nc", C.c_int32), ("R", C.c_int32), ("max_iter", C.c_int32), ("T", C.c_double),
+                ("q", C.c_double * 3), ("r", C.c_double * 2), ("lw", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double)]
 
 
 _lib = None
@@ -60,6 +68,14 @@ def load():
     L.nmpc_shift_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_shift_batch.restype = i32
     L.nmpc_odometry_batch.argtypes = [C.c_int64, vp, vp, vp, i32, vp]; L.nmpc_odometry_batch.restype = i32
     L.nmpc_version.argtypes = []; L.nmpc_version.restype = C.c_char_p
+    lp = C.POINTER(CLidarConfig)
+    for f in ("nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p"):
+        getattr(L, f).argtypes = [lp]; getattr(L, f).restype = i32
+    L.nmpc_lidar_create.argtypes = [lp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32, C.POINTER(vp)]; L.nmpc_lidar_create.restype = i32
+    L.nmpc_lidar_destroy.argtypes = [vp]; L.nmpc_lidar_destroy.restype = i32
+    L.nmpc_lidar_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_lidar_solve_batch.restype = i32
+    L.nmpc_lidar_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_lidar_eval_batch.restype = i32
+    L.nmpc_lidar_shift_batch.argtypes = [vp, i32, vp, vp, vp]; L.nmpc_lidar_shift_batch.restype = i32
     _lib = L
     return L
 

@@ -8,8 +8,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnmpc_hip.so")
-SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_api.cpp"]
-DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h", os.path.join("..", "..", "include", "nmpc.h")]
+SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_lidar.hip", "nmpc_api.cpp"]
+DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h", os.path.join("..", "..", "include", "nmpc.h"), os.path.join("..", "..", "include", "nmpc_lidar.h")]
 
 
 def _hipcc() -> str:

@@ -1,0 +1,651 @@
+// nmpc_lidar.hip — LIDAR-ray distance-state NMPC solve for gfx950 (include/nmpc_lidar.h).
+//
+// Reference blocks replaced (V4 = AllScripts/obs_avoid_static_first_scenario_v4.py; V3 = ..._v3.py is Nc = N, lw = 0):
+//   NLP V4:78-151 (13 states per stage [x y theta d_1..d_10], move blocking U[:, min(k, Nc-1)], stage cost + 0.1 sum 1/d^2,
+//   rows gx then gd with the 1-norm distance to the lidar points of stage 0), nlpsol('ipopt') V4:156-157 and the call V4:245.
+//
+// Mapping.  This NLP has ONE robot: the pose block is 3 x 3, the control block 2 x 2, and the R distance states of a stage are
+// eliminated through their own linearised equality rows (d = ||p - pObs||_1), so the Newton system is a 3-state Riccati
+// recursion whose matrices (5 x 5 with the held control of the move-blocked stages) fit the registers of ONE LANE.  One lane
+// therefore solves one instance (64 instances per wavefront, no cross-lane traffic at all) and the batch supplies the
+// parallelism; the iterate (13 x 101 states, slacks and duals of every bounded variable, multipliers, step) lives in the
+// instance's workspace in HBM in structure-of-arrays order — element e of instance b at ws[e * S + b] — so that every access of a
+// wavefront is one coalesced 512-byte segment.  Algorithm: the interior-point iteration of nmpc_kernels.hip / the oracle
+// (barrier rule, fraction to the boundary, non-monotone l1-merit search, inertia shift on the control diagonal, barrier restart).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/nmpc_lidar.h"
+
+namespace nmpc_lidar {
+
+struct LParams {
+    int32_t N, Nc, R, ns, max_iter, nvar, ng, np;
+    double T, q[3], r[2], lw, tol, mu_init;
+    const double *lb, *ub;      // device copies of the caller's lbx / ubx [n_var]
+    int64_t S;                  // instance stride of the structure-of-arrays workspace (batch rounded up to 64)
+    // element offsets of the per-instance arrays
+    int64_t oV, oU, olam, oeta, oSL, oZL, oSU, oZU, oSLu, oZLu, oSUu, oZUu, odV, odU, olamn, oetan, oVt, oUt, osn, ocs, oHxx, ogx, oWd,
+        ogdv, ohuu, ogu, ohvt, oKg, okff, opo, total;
+};
+
+#define W_(off, i) ws[((size_t)(off) + (size_t)(i)) * S + b]
+
+__device__ __forceinline__ double sgn(double a) { return (double)((a > 0.0) - (a < 0.0)); }
+
+__device__ __forceinline__ double push_in(double v, double lo, double hi)
+{
+    const double bp = 1e-2;
+    if (isfinite(lo) && isfinite(hi)) {
+        double pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo)), qu = fmin(bp * fmax(1.0, fabs(hi)), bp * (hi - lo));
+        return fmin(fmax(v, lo + pu), hi - qu);
+    }
+    if (isfinite(lo)) return fmax(v, lo + bp * fmax(1.0, fabs(lo)));
+    if (isfinite(hi)) return fmin(v, hi - bp * fmax(1.0, fabs(hi)));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
+                                                          double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
+                                                          int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int N = P.N, Nc = P.Nc, R = P.R, ns = P.ns;
+    const size_t S = (size_t)P.S;
+    const double T = P.T;
+    const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
+    double *wo = w_out + (size_t)b * P.nvar;
+    const double *lbv = P.lb, *ubv = P.ub, *lbu = P.lb + (size_t)(N + 1) * ns, *ubu = P.ub + (size_t)(N + 1) * ns;
+    int64_t oV = P.oV, oVt = P.oVt, oU = P.oU, oUt = P.oUt;
+    const double xs0 = pp[3], xs1 = pp[4], xs2 = pp[5];
+    auto cof = [&](int k) { return k < Nc - 1 ? k : Nc - 1; };
+    auto gdist = [&](int m, double x, double y, double &sx, double &sy) {
+        double ax = x - W_(P.opo, 2 * m), ay = y - W_(P.opo, 2 * m + 1);
+        sx = sgn(ax); sy = sgn(ay);
+        return fabs(ax) + fabs(ay);
+    };
+    // ---- load the start; X_0 (pose and scan) pinned to the parameters (V4:110-111); lidar points (V4:114-118)
+    for (int e = 0; e < (N + 1) * ns; e++) W_(oV, e) = wi[e];
+    for (int e = 0; e < 2 * Nc; e++) W_(oU, e) = wi[(size_t)(N + 1) * ns + e];
+    for (int i = 0; i < 3; i++) W_(oV, i) = pp[i];
+    for (int m = 0; m < R; m++) {
+        W_(oV, 3 + m) = pp[6 + m];
+        double a = pp[2] + pp[6 + R + m], s, c;
+        sincos(a, &s, &c);
+        W_(P.opo, 2 * m) = pp[0] + pp[6 + m] * c; W_(P.opo, 2 * m + 1) = pp[1] + pp[6 + m] * s;
+    }
+    {   // the pinned stage-0 variables must respect their own bounds
+        bool bad = false;
+        for (int c = 0; c < ns; c++) { double v = W_(oV, c); if (v < lbv[c] || v > ubv[c]) bad = true; }
+        if (bad) {
+            for (int e = 0; e < (N + 1) * ns; e++) wo[e] = W_(oV, e);
+            for (int e = 0; e < 2 * Nc; e++) wo[(size_t)(N + 1) * ns + e] = W_(oU, e);
+            if (obj_out) obj_out[b] = NAN;
+            if (status_out) status_out[b] = NMPC_STATUS_INFEASIBLE_X0;
+            if (iters_out) iters_out[b] = 0;
+            if (kkt_out) kkt_out[b] = INFINITY;
+            return;
+        }
+    }
+    int n_ineq = 4 * Nc;
+    for (int e = ns; e < (N + 1) * ns; e++) n_ineq += (isfinite(lbv[e]) ? 1 : 0) + (isfinite(ubv[e]) ? 1 : 0);
+
+    // objective, sum / max of the equality residuals at (oVx, oUx); optionally the trig cache
+    auto eval_point = [&](int64_t oVx, int64_t oUx, bool trig, double &th, double &ec) {
+        double f = 0.0; th = 0.0; ec = 0.0;
+        for (int k = 0; k < N; k++) {
+            const int j = cof(k);
+            const double x = W_(oVx, k * ns), y = W_(oVx, k * ns + 1), t = W_(oVx, k * ns + 2), u0 = W_(oUx, 2 * j), u1 = W_(oUx, 2 * j + 1);
+            const double xn = W_(oVx, (k + 1) * ns), yn = W_(oVx, (k + 1) * ns + 1), tn = W_(oVx, (k + 1) * ns + 2);
+            double s, c;
+            sincos(t, &s, &c);
+            if (trig) { W_(P.osn, k) = s; W_(P.ocs, k) = c; }
+            const double c0 = xn - (x + T * u0 * c), c1 = yn - (y + T * u0 * s), c2 = tn - (t + T * u1);
+            th += fabs(c0) + fabs(c1) + fabs(c2); ec = fmax(ec, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
+            f += P.q[0] * (x - xs0) * (x - xs0); f += P.q[1] * (y - xs1) * (y - xs1); f += P.q[2] * (t - xs2) * (t - xs2);
+            f += P.r[0] * u0 * u0 + P.r[1] * u1 * u1;
+            for (int m = 0; m < R; m++) {
+                if (P.lw != 0.0) { double d = W_(oVx, k * ns + 3 + m); f += P.lw / (d * d); }
+                double sx, sy, e = W_(oVx, (k + 1) * ns + 3 + m) - gdist(m, xn, yn, sx, sy);
+                th += fabs(e); ec = fmax(ec, fabs(e));
+            }
+        }
+        return f;
+    };
+
+    double mu = P.mu_init, f = 0.0, th0 = 0.0, e_c = 0.0;
+    int it = 0, n_tiny = 0, n_restart = 0, status = NMPC_STATUS_MAX_ITER;
+    bool need_shift = false, restarting = false;
+    double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
+    double mh0 = 0, mh1 = 0, mh2 = 0, mh_mu = -1, mh_nu = -1;
+    int mcount = 0;
+
+    for (;;) {      // (re)start of the barrier iteration
+        for (int e = ns; e < (N + 1) * ns; e++) W_(oV, e) = push_in(W_(oV, e), lbv[e], ubv[e]);
+        for (int e = 0; e < 2 * Nc; e++) W_(oU, e) = push_in(W_(oU, e), lbu[e], ubu[e]);
+        for (int e = ns; e < (N + 1) * ns; e++) {
+            const double lo = lbv[e], hi = ubv[e], v = W_(oV, e);
+            const double sl = isfinite(lo) ? fmax(v - lo, 1e-12) : 1.0, su = isfinite(hi) ? fmax(hi - v, 1e-12) : 1.0;
+            W_(P.oSL, e) = sl; W_(P.oZL, e) = isfinite(lo) ? mu / sl : 0.0;
+            W_(P.oSU, e) = su; W_(P.oZU, e) = isfinite(hi) ? mu / su : 0.0;
+        }
+        for (int e = 0; e < 2 * Nc; e++) {
+            const double u = W_(oU, e), sl = fmax(u - lbu[e], 1e-12), su = fmax(ubu[e] - u, 1e-12);
+            W_(P.oSLu, e) = sl; W_(P.oZLu, e) = mu / sl; W_(P.oSUu, e) = su; W_(P.oZUu, e) = mu / su;
+        }
+        for (int e = 0; e < (N + 1) * 3; e++) W_(P.olam, e) = 0.0;
+        for (int e = 0; e < (N + 1) * R; e++) W_(P.oeta, e) = 0.0;
+        f = eval_point(oV, oU, true, th0, e_c);
+        delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false;
+
+        for (;;) {
+            // ---- A. optimality error (IPOPT eq. 5)
+            double e_d = 0.0, e_h = 0.0, zsum = 0.0, lsum = 0.0, cmax = 0.0, cmin = INFINITY;
+            for (int k = 1; k <= N; k++) {
+                const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1), t = W_(oV, k * ns + 2);
+                double r0 = W_(P.olam, 3 * k), r1 = W_(P.olam, 3 * k + 1), r2 = W_(P.olam, 3 * k + 2);
+                lsum += fabs(r0) + fabs(r1) + fabs(r2);
+                if (k < N) {
+                    const double l0 = W_(P.olam, 3 * k + 3), l1 = W_(P.olam, 3 * k + 4), l2 = W_(P.olam, 3 * k + 5), u0 = W_(oU, 2 * cof(k));
+                    const double a = -T * u0 * W_(P.osn, k), bq = T * u0 * W_(P.ocs, k);
+                    r0 += 2 * P.q[0] * (x - xs0) - l0; r1 += 2 * P.q[1] * (y - xs1) - l1; r2 += 2 * P.q[2] * (t - xs2) - l2;
+                    r2 -= a * l0 + bq * l1;
+                }
+                for (int m = 0; m < R; m++) {
+                    double sx, sy; gdist(m, x, y, sx, sy);
+                    const double et = W_(P.oeta, k * R + m), d = W_(oV, k * ns + 3 + m);
+                    r0 -= et * sx; r1 -= et * sy;
+                    double rd = et + ((k < N && P.lw != 0.0) ? -2.0 * P.lw / (d * d * d) : 0.0);
+                    rd -= W_(P.oZL, k * ns + 3 + m) - W_(P.oZU, k * ns + 3 + m);
+                    e_d = fmax(e_d, fabs(rd)); lsum += fabs(et);
+                }
+                r0 -= W_(P.oZL, k * ns) - W_(P.oZU, k * ns); r1 -= W_(P.oZL, k * ns + 1) - W_(P.oZU, k * ns + 1); r2 -= W_(P.oZL, k * ns + 2) - W_(P.oZU, k * ns + 2);
+                e_d = fmax(e_d, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
+                for (int c = 0; c < ns; c++) {
+                    const int e = k * ns + c;
+                    const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
+                    if (isfinite(lo)) { double sl = W_(P.oSL, e), zl = W_(P.oZL, e), pz = sl * zl; zsum += zl; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((v - lo) - sl)); }
+                    if (isfinite(hi)) { double su = W_(P.oSU, e), zu = W_(P.oZU, e), pz = su * zu; zsum += zu; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((hi - v) - su)); }
+                }
+            }
+            for (int j = 0; j < Nc; j++) {
+                double ru0 = 0.0, ru1 = 0.0;
+                const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1);
+                for (int k = j; k < N; k++) {
+                    if (cof(k) != j) break;
+                    ru0 += 2 * P.r[0] * u0 - T * (W_(P.ocs, k) * W_(P.olam, 3 * k + 3) + W_(P.osn, k) * W_(P.olam, 3 * k + 4));
+                    ru1 += 2 * P.r[1] * u1 - T * W_(P.olam, 3 * k + 5);
+                }
+                for (int e = 0; e < 2; e++) {
+                    const int o = 2 * j + e;
+                    const double zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), sl = W_(P.oSLu, o), su = W_(P.oSUu, o), u = e ? u1 : u0;
+                    const double ru = (e ? ru1 : ru0) - (zl - zu);
+                    e_d = fmax(e_d, fabs(ru)); zsum += zl + zu;
+                    cmax = fmax(cmax, fmax(sl * zl, su * zu)); cmin = fmin(cmin, fmin(sl * zl, su * zu));
+                    e_h = fmax(e_h, fmax(fabs((u - lbu[o]) - sl), fabs((ubu[o] - u) - su)));
+                }
+            }
+            const double smax = 100.0;
+            const double s_d = fmax(smax, (lsum + zsum) / (double)(N * ns + n_ineq)) / smax;
+            const double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
+            const double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c));
+            kkt = E0;
+            if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+            if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
+            if (it >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+            const double mu_min = P.tol / 10.0;
+            for (;;) {
+                const double cm = fmax(fabs(cmax - mu), fabs(cmin - mu));
+                const double Emu = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cm / s_c));
+                if (mu > mu_min && Emu <= 10.0 * mu) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
+                else break;
+            }
+            const double tau = fmax(0.99, 1.0 - mu);
+
+            // ---- B0. condensed stage blocks.  slot: v = mu/s - sigma (h - s), sigma = z/s
+            for (int k = 1; k <= N; k++) {
+                const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1);
+                double H0 = 0.0, H1 = 0.0, H2 = 0.0, hd[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+                if (k < N) {
+                    hd[0] = 2 * P.q[0]; hd[1] = 2 * P.q[1]; hd[2] = 2 * P.q[2];
+                    g[0] = 2 * P.q[0] * (x - xs0); g[1] = 2 * P.q[1] * (y - xs1); g[2] = 2 * P.q[2] * (W_(oV, k * ns + 2) - xs2);
+                }
+                for (int c = 0; c < ns; c++) {
+                    const int e = k * ns + c;
+                    const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
+                    double hs = 0.0, gs = 0.0;
+                    if (isfinite(lo)) { double sl = W_(P.oSL, e), sg = W_(P.oZL, e) / sl; hs += sg; gs -= mu / sl - sg * ((v - lo) - sl); }
+                    if (isfinite(hi)) { double su = W_(P.oSU, e), sg = W_(P.oZU, e) / su; hs += sg; gs += mu / su - sg * ((hi - v) - su); }
+                    if (c < 3) { hd[c] += hs; g[c] += gs; }
+                    else {
+                        const int m = c - 3;
+                        const bool cost = k < N && P.lw != 0.0;
+                        const double Wd = hs + (cost ? 6.0 * P.lw / (v * v * v * v) : 0.0), gd = gs + (cost ? -2.0 * P.lw / (v * v * v) : 0.0);
+                        W_(P.oWd, k * R + m) = Wd; W_(P.ogdv, k * R + m) = gd;
+                        double sx, sy;
+                        const double re = gdist(m, x, y, sx, sy) - v, tq = gd + Wd * re;      // linearised row: dd = G dx + re
+                        g[0] += sx * tq; g[1] += sy * tq;
+                        H0 += Wd * sx * sx; H1 += Wd * sx * sy; H2 += Wd * sy * sy;
+                    }
+                }
+                double H3 = hd[2];
+                if (k < N) H3 += T * W_(oU, 2 * cof(k)) * (W_(P.olam, 3 * k + 3) * W_(P.ocs, k) + W_(P.olam, 3 * k + 4) * W_(P.osn, k));
+                W_(P.oHxx, 4 * k) = H0 + hd[0]; W_(P.oHxx, 4 * k + 1) = H1; W_(P.oHxx, 4 * k + 2) = H2 + hd[1]; W_(P.oHxx, 4 * k + 3) = H3;
+                W_(P.ogx, 3 * k) = g[0]; W_(P.ogx, 3 * k + 1) = g[1]; W_(P.ogx, 3 * k + 2) = g[2];
+            }
+            for (int k = 0; k < N; k++) W_(P.ohvt, k) = T * (W_(P.olam, 3 * k + 3) * W_(P.osn, k) - W_(P.olam, 3 * k + 4) * W_(P.ocs, k));
+            for (int o = 0; o < 2 * Nc; o++) {
+                const int j = o >> 1, e = o & 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
+                const double sl = W_(P.oSLu, o), su = W_(P.oSUu, o), zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), u = W_(oU, o);
+                W_(P.ohuu, o) = cnt * 2 * P.r[e] + zl / sl + zu / su;
+                const double vl = mu / sl - zl / sl * ((u - lbu[o]) - sl), vu = mu / su - zu / su * ((ubu[o] - u) - su);
+                W_(P.ogu, o) = cnt * 2 * P.r[e] * u - (vl - vu);
+            }
+
+            // ---- B. Riccati sweep on z = (pose (3), held control (2)) with inertia correction; everything of a stage in registers
+            double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
+            int ntry = 0;
+            bool ok;
+            for (;;) {
+                ok = true;
+                double P5[25], p5[5];
+#pragma unroll
+                for (int z = 0; z < 25; z++) P5[z] = 0.0;
+#pragma unroll
+                for (int z = 0; z < 5; z++) p5[z] = 0.0;
+                P5[0] = W_(P.oHxx, 4 * N); P5[1] = P5[5] = W_(P.oHxx, 4 * N + 1); P5[6] = W_(P.oHxx, 4 * N + 2); P5[12] = W_(P.oHxx, 4 * N + 3);
+                p5[0] = W_(P.ogx, 3 * N); p5[1] = W_(P.ogx, 3 * N + 1); p5[2] = W_(P.ogx, 3 * N + 2);
+                for (int k = N - 1; k >= 0; k--) {
+                    const int j = cof(k);
+                    const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1), s = W_(P.osn, k), c = W_(P.ocs, k), a = -T * u0 * s, bq = T * u0 * c;
+                    const double cd0 = W_(oV, (k + 1) * ns) - (W_(oV, k * ns) + T * u0 * c), cd1 = W_(oV, (k + 1) * ns + 1) - (W_(oV, k * ns + 1) + T * u0 * s),
+                                 cd2 = W_(oV, (k + 1) * ns + 2) - (W_(oV, k * ns + 2) + T * u1);
+                    // At = [[A, B], [0, I]] acts on columns, then on rows: G = P At, M = At^T G (At is sparse: written out)
+                    double pb[5], G5[25], Mx[25], mv[5];
+#pragma unroll
+                    for (int r_ = 0; r_ < 5; r_++) {
+                        pb[r_] = p5[r_] - (P5[r_ * 5] * cd0 + P5[r_ * 5 + 1] * cd1 + P5[r_ * 5 + 2] * cd2);
+                        const double c0_ = P5[r_ * 5], c1_ = P5[r_ * 5 + 1], c2_ = P5[r_ * 5 + 2], c3_ = P5[r_ * 5 + 3], c4_ = P5[r_ * 5 + 4];
+                        G5[r_ * 5] = c0_; G5[r_ * 5 + 1] = c1_; G5[r_ * 5 + 2] = a * c0_ + bq * c1_ + c2_;
+                        G5[r_ * 5 + 3] = T * c * c0_ + T * s * c1_ + c3_; G5[r_ * 5 + 4] = T * c2_ + c4_;
+                    }
+#pragma unroll
+                    for (int q_ = 0; q_ < 5; q_++) {
+                        const double r0_ = G5[q_], r1_ = G5[5 + q_], r2_ = G5[10 + q_], r3_ = G5[15 + q_], r4_ = G5[20 + q_];
+                        Mx[q_] = r0_; Mx[5 + q_] = r1_; Mx[10 + q_] = a * r0_ + bq * r1_ + r2_;
+                        Mx[15 + q_] = T * c * r0_ + T * s * r1_ + r3_; Mx[20 + q_] = T * r2_ + r4_;
+                    }
+                    mv[0] = pb[0]; mv[1] = pb[1]; mv[2] = a * pb[0] + bq * pb[1] + pb[2]; mv[3] = T * c * pb[0] + T * s * pb[1] + pb[3]; mv[4] = T * pb[2] + pb[4];
+                    if (k >= 1) {
+                        const double h1 = W_(P.oHxx, 4 * k + 1);
+                        Mx[0] += W_(P.oHxx, 4 * k); Mx[1] += h1; Mx[5] += h1; Mx[6] += W_(P.oHxx, 4 * k + 2); Mx[12] += W_(P.oHxx, 4 * k + 3);
+                        mv[0] += W_(P.ogx, 3 * k); mv[1] += W_(P.ogx, 3 * k + 1); mv[2] += W_(P.ogx, 3 * k + 2);
+                    }
+                    { const double hv = W_(P.ohvt, k); Mx[2 * 5 + 3] += hv; Mx[3 * 5 + 2] += hv; }
+                    if (k <= Nc - 1) {        // the stage where control j is decided carries its whole diagonal / gradient
+                        Mx[18] += W_(P.ohuu, 2 * j) + delta; Mx[24] += W_(P.ohuu, 2 * j + 1) + delta;
+                        mv[3] += W_(P.ogu, 2 * j); mv[4] += W_(P.ogu, 2 * j + 1);
+                        const double dv = Mx[18];
+                        if (!(dv > 0.0)) { ok = false; break; }
+                        const double l43 = Mx[23] / dv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
+                        if (!(d1 > 1e-9 * fabs(d1o)) || !(d1 > 0.0)) { ok = false; break; }
+                        double Kk[6], kk[2];
+#pragma unroll
+                        for (int q_ = 0; q_ < 4; q_++) {
+                            const double r3 = (q_ < 3) ? Mx[15 + q_] : mv[3], r4 = (q_ < 3) ? Mx[20 + q_] : mv[4];
+                            const double y4 = (r4 - l43 * r3) / d1, y3 = (r3 - Mx[19] * y4) / dv;
+                            if (q_ < 3) { Kk[q_] = -y3; Kk[3 + q_] = -y4; } else { kk[0] = -y3; kk[1] = -y4; }
+                        }
+#pragma unroll
+                        for (int q_ = 0; q_ < 6; q_++) W_(P.oKg, 6 * j + q_) = Kk[q_];
+                        W_(P.okff, 2 * j) = kk[0]; W_(P.okff, 2 * j + 1) = kk[1];
+                        double Pn[9], pn[3];
+#pragma unroll
+                        for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+                            for (int q_ = 0; q_ < 3; q_++) Pn[r_ * 3 + q_] = Mx[r_ * 5 + q_] + Mx[r_ * 5 + 3] * Kk[q_] + Mx[r_ * 5 + 4] * Kk[3 + q_];
+                            pn[r_] = mv[r_] + Mx[r_ * 5 + 3] * kk[0] + Mx[r_ * 5 + 4] * kk[1];
+                        }
+#pragma unroll
+                        for (int z = 0; z < 25; z++) P5[z] = 0.0;
+#pragma unroll
+                        for (int z = 0; z < 5; z++) p5[z] = 0.0;
+#pragma unroll
+                        for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+                            for (int q_ = 0; q_ < 3; q_++) P5[r_ * 5 + q_] = 0.5 * (Pn[r_ * 3 + q_] + Pn[q_ * 3 + r_]);
+                            p5[r_] = pn[r_];
+                        }
+                    } else {                  // held control: it stays a parameter of the cost-to-go
+#pragma unroll
+                        for (int r_ = 0; r_ < 5; r_++) {
+#pragma unroll
+                            for (int q_ = 0; q_ < 5; q_++) P5[r_ * 5 + q_] = (q_ == r_) ? Mx[r_ * 5 + q_] : 0.5 * (Mx[r_ * 5 + q_] + Mx[q_ * 5 + r_]);
+                            p5[r_] = mv[r_];
+                        }
+                    }
+                }
+                if (ok) break;
+                ntry++;
+                if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
+                else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+                if (delta > 1e20) break;
+            }
+            if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+            if (delta > 0.0) delta_last = delta;
+            need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
+
+            // ---- C. forward sweep
+            for (int c = 0; c < ns; c++) W_(P.odV, c) = 0.0;
+            {
+                double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
+                for (int k = 0; k < N; k++) {
+                    const int j = cof(k);
+                    if (k <= Nc - 1) {
+                        du0 = W_(P.okff, 2 * j) + W_(P.oKg, 6 * j) * dx0 + W_(P.oKg, 6 * j + 1) * dx1 + W_(P.oKg, 6 * j + 2) * dx2;
+                        du1 = W_(P.okff, 2 * j + 1) + W_(P.oKg, 6 * j + 3) * dx0 + W_(P.oKg, 6 * j + 4) * dx1 + W_(P.oKg, 6 * j + 5) * dx2;
+                        W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1;
+                    }
+                    const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1), s = W_(P.osn, k), c = W_(P.ocs, k);
+                    const double xn = W_(oV, (k + 1) * ns), yn = W_(oV, (k + 1) * ns + 1), tn = W_(oV, (k + 1) * ns + 2);
+                    const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (xn - (W_(oV, k * ns) + T * u0 * c));
+                    const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (yn - (W_(oV, k * ns + 1) + T * u0 * s));
+                    const double n2 = dx2 + T * du1 - (tn - (W_(oV, k * ns + 2) + T * u1));
+                    dx0 = n0; dx1 = n1; dx2 = n2;
+                    W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2;
+                    for (int m = 0; m < R; m++) {     // dd = G dx + (g - d) at stage k+1
+                        double sx, sy;
+                        const double gg = gdist(m, xn, yn, sx, sy);
+                        W_(P.odV, (k + 1) * ns + 3 + m) = sx * n0 + sy * n1 + (gg - W_(oV, (k + 1) * ns + 3 + m));
+                    }
+                }
+            }
+            // ---- multipliers of the QP: eta+ from the distance rows, lambda+ by the adjoint recursion
+            double mult_max = 0.0;
+            {
+                double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
+                for (int k = N; k >= 1; k--) {
+                    const double dx0 = W_(P.odV, k * ns), dx1 = W_(P.odV, k * ns + 1), dx2 = W_(P.odV, k * ns + 2);
+                    const double H0 = W_(P.oHxx, 4 * k), H1 = W_(P.oHxx, 4 * k + 1), H2 = W_(P.oHxx, 4 * k + 2), H3 = W_(P.oHxx, 4 * k + 3);
+                    double l0 = -(W_(P.ogx, 3 * k) + H0 * dx0 + H1 * dx1), l1 = -(W_(P.ogx, 3 * k + 1) + H1 * dx0 + H2 * dx1), l2 = -(W_(P.ogx, 3 * k + 2) + H3 * dx2);
+                    if (k < N) {
+                        const int j = cof(k);
+                        const double u0 = W_(oU, 2 * j);
+                        l0 += ln0; l1 += ln1;
+                        l2 += ln2 + (-T * u0 * W_(P.osn, k)) * ln0 + (T * u0 * W_(P.ocs, k)) * ln1 - W_(P.ohvt, k) * W_(P.odU, 2 * j);
+                    }
+                    ln0 = l0; ln1 = l1; ln2 = l2;
+                    W_(P.olamn, 3 * k) = l0; W_(P.olamn, 3 * k + 1) = l1; W_(P.olamn, 3 * k + 2) = l2;
+                    mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
+                    for (int m = 0; m < R; m++) {
+                        const double e = -(W_(P.ogdv, k * R + m) + W_(P.oWd, k * R + m) * W_(P.odV, k * ns + 3 + m));
+                        W_(P.oetan, k * R + m) = e; mult_max = fmax(mult_max, fabs(e));
+                    }
+                }
+            }
+            // ---- D. fraction to the boundary; directional derivative of the barrier function
+            double a_p = 1.0, a_d = 1.0, dphi = 0.0, lgs = 0.0, thh = 0.0;
+            auto slot = [&](double s_, double z_, double h_, double jd_) {
+                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
+                if (ds_ < 0.0) a_p = fmin(a_p, -tau * s_ / ds_);
+                if (dz_ < 0.0) a_d = fmin(a_d, -tau * z_ / dz_);
+                dphi -= mu * ds_ / s_; lgs += log(s_); thh += fabs(h_ - s_);
+            };
+            for (int e = ns; e < (N + 1) * ns; e++) {
+                const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
+                if (isfinite(lo)) slot(W_(P.oSL, e), W_(P.oZL, e), v - lo, dv);
+                if (isfinite(hi)) slot(W_(P.oSU, e), W_(P.oZU, e), hi - v, -dv);
+            }
+            for (int o = 0; o < 2 * Nc; o++) {
+                const double u = W_(oU, o), du = W_(P.odU, o);
+                slot(W_(P.oSLu, o), W_(P.oZLu, o), u - lbu[o], du);
+                slot(W_(P.oSUu, o), W_(P.oZUu, o), ubu[o] - u, -du);
+            }
+            for (int k = 1; k < N; k++) {
+                dphi += 2 * P.q[0] * (W_(oV, k * ns) - xs0) * W_(P.odV, k * ns); dphi += 2 * P.q[1] * (W_(oV, k * ns + 1) - xs1) * W_(P.odV, k * ns + 1);
+                dphi += 2 * P.q[2] * (W_(oV, k * ns + 2) - xs2) * W_(P.odV, k * ns + 2);
+                if (P.lw != 0.0)
+                    for (int m = 0; m < R; m++) { const double d = W_(oV, k * ns + 3 + m); dphi += -2.0 * P.lw / (d * d * d) * W_(P.odV, k * ns + 3 + m); }
+            }
+            for (int o = 0; o < 2 * Nc; o++) { const int j = o >> 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1; dphi += cnt * 2 * P.r[o & 1] * W_(oU, o) * W_(P.odU, o); }
+            // ---- E. l1 merit backtracking (non-monotone reference: max of the last merit values of this barrier problem)
+            const double theta0 = th0 + thh, phi0 = f - mu * lgs;
+            if (theta0 > 0.0) {
+                const double nut = fmin(dphi / ((1.0 - 0.1) * theta0), mult_max / (1.0 - 0.1));
+                nu_pen = fmax(1.0, 0.5 * nu_pen);
+                if (nu_pen < nut) nu_pen = nut + 1.0;
+            }
+            const double Dm = dphi - nu_pen * theta0;
+            double alpha = a_p, ft = f, tht = th0, ect = e_c;
+            if (mh_mu != mu || mh_nu != nu_pen) { mcount = 0; mh_mu = mu; mh_nu = nu_pen; }
+            const double m0 = phi0 + nu_pen * theta0;
+            double mref = m0;
+            if (mcount > 0) mref = fmax(mref, mh0);
+            if (mcount > 1) mref = fmax(mref, mh1);
+            if (mcount > 2) mref = fmax(mref, mh2);
+            mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
+            for (int ls = 0; ls < 30; ls++) {
+                for (int e = 0; e < (N + 1) * ns; e++) W_(oVt, e) = W_(oV, e) + alpha * W_(P.odV, e);
+                for (int e = 0; e < 2 * Nc; e++) W_(oUt, e) = W_(oU, e) + alpha * W_(P.odU, e);
+                ft = eval_point(oVt, oUt, false, tht, ect);
+                double lgt = 0.0, tb = 0.0;
+                auto trial = [&](double s_, double h0_, double jd_, double ht_) { const double st_ = s_ + alpha * (jd_ + (h0_ - s_)); lgt += log(st_); tb += fabs(ht_ - st_); };
+                for (int e = ns; e < (N + 1) * ns; e++) {
+                    const double v = W_(oV, e), dv = W_(P.odV, e), vt = W_(oVt, e), lo = lbv[e], hi = ubv[e];
+                    if (isfinite(lo)) trial(W_(P.oSL, e), v - lo, dv, vt - lo);
+                    if (isfinite(hi)) trial(W_(P.oSU, e), hi - v, -dv, hi - vt);
+                }
+                for (int o = 0; o < 2 * Nc; o++) {
+                    const double u = W_(oU, o), du = W_(P.odU, o), ut = W_(oUt, o);
+                    trial(W_(P.oSLu, o), u - lbu[o], du, ut - lbu[o]);
+                    trial(W_(P.oSUu, o), ubu[o] - u, -du, ubu[o] - ut);
+                }
+                if ((ft - mu * lgt) + nu_pen * (tht + tb) <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
+                if (ls < 29) alpha *= 0.5;
+            }
+            a_d = fmin(a_d, alpha);
+            n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
+            // ---- G. accept: duals and slacks (they need the old primal point), then the primal point
+            auto upd = [&](int64_t oS, int64_t oZ, int e, double h_, double jd_) {
+                const double s_ = W_(oS, e), z_ = W_(oZ, e);
+                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
+                const double sn_ = s_ + alpha * ds_, zn_ = z_ + a_d * dz_;
+                W_(oS, e) = sn_; W_(oZ, e) = fmin(fmax(zn_, mu / (1e10 * sn_)), 1e10 * mu / sn_);
+            };
+            for (int e = ns; e < (N + 1) * ns; e++) {
+                const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
+                if (isfinite(lo)) upd(P.oSL, P.oZL, e, v - lo, dv);
+                if (isfinite(hi)) upd(P.oSU, P.oZU, e, hi - v, -dv);
+            }
+            for (int o = 0; o < 2 * Nc; o++) {
+                const double u = W_(oU, o), du = W_(P.odU, o);
+                upd(P.oSLu, P.oZLu, o, u - lbu[o], du);
+                upd(P.oSUu, P.oZUu, o, ubu[o] - u, -du);
+            }
+            { int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_; }
+            for (int e = 3; e < (N + 1) * 3; e++) W_(P.olam, e) += alpha * (W_(P.olamn, e) - W_(P.olam, e));
+            for (int e = R; e < (N + 1) * R; e++) W_(P.oeta, e) += alpha * (W_(P.oetan, e) - W_(P.oeta, e));
+            f = eval_point(oV, oU, true, th0, e_c);
+            it++;
+            if (n_tiny >= 5) {
+                if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+                n_restart++; n_tiny = 0; mu = fmax(mu, P.mu_init); restarting = true;
+                break;
+            }
+        }
+        if (!restarting) break;
+    }
+    for (int e = 0; e < (N + 1) * ns; e++) wo[e] = W_(oV, e);
+    for (int e = 0; e < 2 * Nc; e++) wo[(size_t)(N + 1) * ns + e] = W_(oU, e);
+    if (obj_out) obj_out[b] = f;
+    if (status_out) status_out[b] = status;
+    if (iters_out) iters_out[b] = it;
+    if (kkt_out) kkt_out[b] = kkt;
+}
+
+// f (V4:135-136) and g = [gx; gd] (V4:151): one thread per (instance, stage); stage N handles the initial rows
+__global__ __launch_bounds__(256) void lidar_eval_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w,
+                                                          double *__restrict__ f_out, double *__restrict__ g_out)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = P.N, R = P.R, ns = P.ns;
+    if (gid >= (long)B * (N + 1)) return;
+    const int b = (int)(gid / (N + 1)), k = (int)(gid - (long)b * (N + 1));
+    const double *X = w + (size_t)b * P.nvar, *U = X + (size_t)(N + 1) * ns, *pp = p_in + (size_t)b * P.np;
+    double *gx = g_out ? g_out + (size_t)b * P.ng : nullptr, *gd = g_out ? gx + 3 * (N + 1) : nullptr;
+    if (k == N) {
+        if (g_out) { for (int i = 0; i < 3; i++) gx[i] = X[i] - pp[i]; for (int m = 0; m < R; m++) gd[m] = X[3 + m] - pp[6 + m]; }
+        return;
+    }
+    const double *v = X + (size_t)k * ns, *vn = v + ns, *u = U + 2 * (k < P.Nc - 1 ? k : P.Nc - 1);
+    double fs = P.q[0] * (v[0] - pp[3]) * (v[0] - pp[3]) + P.q[1] * (v[1] - pp[4]) * (v[1] - pp[4]) + P.q[2] * (v[2] - pp[5]) * (v[2] - pp[5]) +
+                P.r[0] * u[0] * u[0] + P.r[1] * u[1] * u[1];
+    if (P.lw != 0.0) for (int m = 0; m < R; m++) fs += P.lw / (v[3 + m] * v[3 + m]);
+    if (g_out) {
+        double s, c;
+        sincos(v[2], &s, &c);
+        gx[3 * (k + 1)] = vn[0] - (v[0] + P.T * u[0] * c); gx[3 * (k + 1) + 1] = vn[1] - (v[1] + P.T * u[0] * s); gx[3 * (k + 1) + 2] = vn[2] - (v[2] + P.T * u[1]);
+        for (int m = 0; m < R; m++) {
+            double sa, ca;
+            sincos(X[2] + pp[6 + R + m], &sa, &ca);       // pObs from the STAGE-0 variables of w (V4:114-118)
+            gd[R * (k + 1) + m] = vn[3 + m] - (fabs(vn[0] - (X[0] + X[3 + m] * ca)) + fabs(vn[1] - (X[1] + X[3 + m] * sa)));
+        }
+    }
+    if (f_out) atomicAdd(&f_out[b], fs);
+}
+
+// warm-start shuffle V4:258-270
+__global__ __launch_bounds__(256) void lidar_shift_kernel(const LParams P, int B, const double *__restrict__ w_in, double *__restrict__ w_next)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * P.nvar) return;
+    const int b = (int)(gid / P.nvar), e = (int)(gid - (long)b * P.nvar), N = P.N, ns = P.ns, nX = (N + 1) * ns;
+    const double *src = w_in + (size_t)b * P.nvar;
+    double v;
+    if (e < nX) { int k = e / ns, c = e - k * ns; v = (k < N) ? src[(k + 1) * ns + c] : src[(N - 1) * ns + c]; }
+    else { int eu = e - nX, j = eu >> 1, c = eu & 1; v = (j < P.Nc - 1) ? src[nX + 2 * (j + 1) + c] : src[nX + 2 * (P.Nc - 1) + c]; }
+    w_next[gid] = v;
+}
+
+}  // namespace nmpc_lidar
+
+struct nmpc_lidar_handle {
+    nmpc_lidar_config_t cfg;
+    nmpc_lidar::LParams P;
+    int32_t max_batch;
+    int device;
+    double *ws, *lb, *ub;
+    int64_t ws_bytes;
+};
+
+extern "C" {
+
+int32_t nmpc_lidar_n_var(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) + 2 * c->Nc : NMPC_E_ARG; }
+int32_t nmpc_lidar_n_g(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) : NMPC_E_ARG; }
+int32_t nmpc_lidar_n_p(const nmpc_lidar_config_t *c) { return c ? 6 + 2 * c->R : NMPC_E_ARG; }
+
+int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, const double *ubx, int32_t max_batch, nmpc_lidar_handle_t **out)
+{
+    if (!cfg || !lbx || !ubx || !out || max_batch < 1) return NMPC_E_ARG;
+    if (cfg->N < 1 || cfg->N > 4096 || cfg->Nc < 1 || cfg->Nc > cfg->N || cfg->R < 0 || cfg->R > NMPC_LIDAR_MAX_RAYS) return NMPC_E_ARG;
+    if (!(cfg->T > 0.0) || !(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0 || !(cfg->lw >= 0.0)) return NMPC_E_ARG;
+    if (!(cfg->q[0] >= 0.0) || !(cfg->q[1] >= 0.0) || !(cfg->q[2] >= 0.0) || !(cfg->r[0] > 0.0) || !(cfg->r[1] > 0.0)) return NMPC_E_ARG;
+    const int nv = nmpc_lidar_n_var(cfg), ns = 3 + cfg->R, N = cfg->N, Nc = cfg->Nc, R = cfg->R;
+    for (int i = 0; i < nv; i++) if (!(lbx[i] < ubx[i])) return NMPC_E_ARG;                                   // NaN or empty interval
+    for (int i = (N + 1) * ns; i < nv; i++) if (!isfinite(lbx[i]) || !isfinite(ubx[i])) return NMPC_E_ARG;   // controls are boxed (V4:166,172)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;   // fail loudly: no CPU path exists
+    nmpc_lidar_handle *h = (nmpc_lidar_handle *)calloc(1, sizeof(nmpc_lidar_handle));
+    if (!h) return NMPC_E_NOMEM;
+    if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
+    h->cfg = *cfg; h->max_batch = max_batch;
+    nmpc_lidar::LParams &P = h->P;
+    memset(&P, 0, sizeof(P));
+    P.N = N; P.Nc = Nc; P.R = R; P.ns = ns; P.max_iter = cfg->max_iter; P.nvar = nv; P.ng = nmpc_lidar_n_g(cfg); P.np = nmpc_lidar_n_p(cfg);
+    P.T = cfg->T; P.lw = cfg->lw; P.tol = cfg->tol; P.mu_init = cfg->mu_init;
+    for (int i = 0; i < 3; i++) P.q[i] = cfg->q[i];
+    for (int i = 0; i < 2; i++) P.r[i] = cfg->r[i];
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t at = o; o += n; return at; };
+    const int64_t nV = (int64_t)(N + 1) * ns, nU = 2 * Nc, nL = (int64_t)(N + 1) * 3, nE = (int64_t)(N + 1) * R;
+    P.oV = take(nV); P.oU = take(nU); P.olam = take(nL); P.oeta = take(nE); P.oSL = take(nV); P.oZL = take(nV); P.oSU = take(nV); P.oZU = take(nV);
+    P.oSLu = take(nU); P.oZLu = take(nU); P.oSUu = take(nU); P.oZUu = take(nU); P.odV = take(nV); P.odU = take(nU); P.olamn = take(nL); P.oetan = take(nE);
+    P.oVt = take(nV); P.oUt = take(nU); P.osn = take(N); P.ocs = take(N); P.oHxx = take(4 * (int64_t)(N + 1)); P.ogx = take(nL); P.oWd = take(nE); P.ogdv = take(nE);
+    P.ohuu = take(nU); P.ogu = take(nU); P.ohvt = take(N); P.oKg = take(6 * (int64_t)Nc); P.okff = take(nU); P.opo = take(2 * R);
+    P.total = o;
+    P.S = ((int64_t)max_batch + 63) / 64 * 64;
+    h->ws_bytes = (int64_t)sizeof(double) * P.total * P.S;
+    if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
+    if (hipMalloc((void **)&h->lb, sizeof(double) * nv) != hipSuccess || hipMalloc((void **)&h->ub, sizeof(double) * nv) != hipSuccess) {
+        (void)hipFree(h->ws); if (h->lb) (void)hipFree(h->lb); free(h); return NMPC_E_NOMEM;
+    }
+    if (hipMemcpy(h->lb, lbx, sizeof(double) * nv, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->ub, ubx, sizeof(double) * nv, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(h->ws); (void)hipFree(h->lb); (void)hipFree(h->ub); free(h); return NMPC_E_HIP;
+    }
+    P.lb = h->lb; P.ub = h->ub;
+    *out = h;
+    return NMPC_OK;
+}
+
+int32_t nmpc_lidar_destroy(nmpc_lidar_handle_t *h)
+{
+    if (!h) return NMPC_E_ARG;
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->lb) (void)hipFree(h->lb);
+    if (h->ub) (void)hipFree(h->ub);
+    free(h);
+    return NMPC_OK;
+}
+
+struct LidarDeviceScope {
+    int prev = -1; bool ok = true, switched = false;
+    explicit LidarDeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; switched = ok; }
+    }
+    ~LidarDeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
+int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
+                               int32_t *iters, double *kkt, void *stream)
+{
+    if (!h || B < 0 || B > h->max_batch) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!p || !w0 || !w_out) return NMPC_E_ARG;
+    LidarDeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
+    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
+    return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_lidar_eval_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream)
+{
+    if (!h || B < 0) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!p || !w) return NMPC_E_ARG;
+    LidarDeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
+    if (f && hipMemsetAsync(f, 0, sizeof(double) * (size_t)B, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
+    const long total = (long)B * (h->P.N + 1);
+    hipLaunchKernelGGL(nmpc_lidar::lidar_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P, B, p, w, f, g);
+    return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_lidar_shift_batch(nmpc_lidar_handle_t *h, int32_t B, const double *w_in, double *w_next, void *stream)
+{
+    if (!h || B < 0) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!w_in || !w_next || w_in == w_next) return NMPC_E_ARG;
+    LidarDeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
+    const long total = (long)B * h->P.nvar;
+    hipLaunchKernelGGL(nmpc_lidar::lidar_shift_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P, B, w_in, w_next);
+    return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+}  // extern "C"

@@ -103,3 +103,65 @@ def shift_batch(cfg: Config, p: np.ndarray, w: np.ndarray, plant: bool = True):
 
 def max_threads() -> int:
     return int(lib().nmpc_oracle_max_threads())
+
+
+# ---- LIDAR-ray distance-state NMPC (oracle/lidar_oracle.c; V4 = AllScripts/obs_avoid_static_first_scenario_v4.py) ------------
+class LidarCConfig(C.Structure):
+    """mirror of nmpc_lidar_config_t (include/nmpc_lidar.h)."""
+    _fields_ = [("N", C.c_int32), ("Nc", C.c_int32), ("R", C.c_int32), ("max_iter", C.c_int32), ("T", C.c_double),
+                ("q", C.c_double * 3), ("r", C.c_double * 2), ("lw", C.c_double), ("tol", C.c_double), ("mu_init", C.c_double)]
+
+
+_LLIB = None
+
+
+def lidar_lib():
+    global _LLIB
+    if _LLIB is None:
+        so = os.path.join(_HERE, "liblidar_oracle.so")
+        src = os.path.join(_HERE, "lidar_oracle.c")
+        hdr = os.path.join(_HERE, "..", "include", "nmpc_lidar.h")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liblidar_oracle.so"], stdout=subprocess.DEVNULL)
+        _LLIB = C.CDLL(so)
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)
+        _LLIB.nmpc_lidar_oracle_solve_batch.argtypes = [C.POINTER(LidarCConfig), dp, dp, C.c_int32, dp, dp, dp, dp, ip, ip, dp, C.c_int32]
+        _LLIB.nmpc_lidar_oracle_solve_batch.restype = C.c_int32
+        _LLIB.nmpc_lidar_oracle_eval_batch.argtypes = [C.POINTER(LidarCConfig), C.c_int32, dp, dp, dp, dp]
+    return _LLIB
+
+
+def lidar_config(cfg, tol=1e-8, mu_init=0.5, max_iter=2000) -> LidarCConfig:
+    """oracle.lidar_ref.LidarConfig -> nmpc_lidar_config_t."""
+    c = LidarCConfig()
+    c.N, c.Nc, c.R, c.max_iter, c.T, c.lw, c.tol, c.mu_init = cfg.N, cfg.Nc, cfg.R, max_iter, cfg.T, cfg.lw, tol, mu_init
+    c.q[:] = cfg.q; c.r[:] = cfg.r
+    return c
+
+
+def lidar_solve_batch(cfg, p, w0, max_iter=2000, nthreads=0, lbx=None, ubx=None):
+    from . import lidar_ref as LR
+    L = lidar_lib()
+    cc = lidar_config(cfg, max_iter=max_iter)
+    if lbx is None:
+        lbx, ubx, _, _ = LR.bounds(cfg)
+    lbx = np.ascontiguousarray(lbx, dtype=np.float64); ubx = np.ascontiguousarray(ubx, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64); w0 = np.ascontiguousarray(w0, dtype=np.float64)
+    B = p.shape[0]
+    assert p.shape == (B, cfg.n_p) and w0.shape == (B, cfg.n_var) and lbx.shape == (cfg.n_var,)
+    w = np.empty((B, cfg.n_var)); obj = np.empty(B); kkt = np.empty(B)
+    st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)
+    rc = L.nmpc_lidar_oracle_solve_batch(C.byref(cc), _dp(lbx), _dp(ubx), B, _dp(p), _dp(w0), _dp(w), _dp(obj),
+                                         st.ctypes.data_as(C.POINTER(C.c_int32)), it.ctypes.data_as(C.POINTER(C.c_int32)), _dp(kkt), nthreads)
+    assert rc == 0, rc
+    return dict(x=w, f=obj, status=st, iters=it, kkt=kkt)
+
+
+def lidar_eval_batch(cfg, p, w):
+    L = lidar_lib()
+    cc = lidar_config(cfg)
+    p = np.ascontiguousarray(p, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64)
+    B = p.shape[0]
+    f = np.empty(B); g = np.empty((B, cfg.n_g))
+    L.nmpc_lidar_oracle_eval_batch(C.byref(cc), B, _dp(p), _dp(w), _dp(f), _dp(g))
+    return f, g

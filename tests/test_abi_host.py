@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_exported(built):
     import nmpc_amd
     hdr = open(os.path.join(ROOT, "include", "nmpc.h")).read()
+    lnames = set(re.findall(r"\b(nmpc_lidar_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "nmpc_lidar.h")).read()))
+    Ll = nmpc_amd._lib.load()
+    assert lnames == set(nmpc_amd._lib.LIDAR_EXPORTS) and all(hasattr(Ll, n) for n in lnames)
     names = set(re.findall(r"\b(nmpc_[a-z_0-9]+)\s*\(", hdr))
     assert {"nmpc_create", "nmpc_destroy", "nmpc_solve_batch", "nmpc_eval_batch", "nmpc_shift_batch"} <= names
     L = nmpc_amd._lib.load()

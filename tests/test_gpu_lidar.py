@@ -1,0 +1,159 @@
+"""-m gpu: the LIDAR-ray distance-state NMPC (V4 = AllScripts/obs_avoid_static_first_scenario_v4.py) —
+the HIP path through the C ABI of include/nmpc_lidar.h against the CPU oracle on the same inputs.
+
+Tolerances: f, g element-wise 1e-12; solve: status equal, max |w_hip - w_oracle| <= 1e-6, |f| relative 1e-6, reported KKT <= 1e-8;
+independent least-squares KKT report on the HIP output."""
+import numpy as np
+import pytest
+
+from oracle import lidar_ref as LR, oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+W_TOL = 1e-6
+
+
+def _world(rng):
+    return [(float(rng.uniform(0.8, 2.6)), float(rng.uniform(0.3, 2.4)), float(rng.uniform(0.15, 0.3))) for _ in range(3)] + \
+           [(float(rng.uniform(-1.5, 0.5)), float(rng.uniform(-1.5, -0.5)), 0.2)]
+
+
+def _batch(cfg, B, seed, goal=(3.0, 2.5, 0.0)):
+    """robots near the origin looking into the first quadrant (the script's start, V4:184), synthetic scans of a random world of
+    circular obstacles, the script's first goal (V4:221)."""
+    rng = np.random.Generator(np.random.PCG64(20210141 + seed))
+    P, W0 = [], []
+    for _ in range(B):
+        if cfg.aligned_bounds:
+            pose = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 1.2)])
+        else:       # the script's misaligned bounds force x, y, theta >= d_min from stage ~24 (V4) / ~29 (V3) on: start where that is reachable
+            pose = np.array([rng.uniform(0.0, 0.15), rng.uniform(0.0, 0.15), rng.uniform(0.4, 1.1)])
+        scan = LR.scan_of_world(pose, _world(rng), cfg.R)
+        xs = np.array(goal) + rng.uniform(-0.3, 0.3, 3)
+        P.append(LR.make_p(cfg, pose, xs, scan)); W0.append(LR.cold_start(cfg, np.concatenate([pose, scan])))
+    return np.stack(P), np.stack(W0)
+
+
+def _product(cfg, **kw):
+    import nmpc_amd
+    return nmpc_amd.LidarProblemConfig(N=cfg.N, Nc=cfg.Nc, R=cfg.R, T=cfg.T, q=tuple(cfg.q), r=tuple(cfg.r), lw=cfg.lw, v_max=cfg.v_max, w_max=cfg.w_max,
+                                       xy_max=cfg.xy_max, th_max=cfg.th_max, d_min=cfg.d_min, d_max=cfg.d_max, **kw)
+
+
+def _np(r):
+    return {k: v.cpu().numpy() for k, v in r.items()}
+
+
+def test_lidar_eval_and_shift_kernels(built):
+    import torch
+    import nmpc_amd
+    rng = np.random.default_rng(3)
+    for cfg in (LR.lidar_v4(), LR.lidar_v3(20), LR.LidarConfig(N=7, Nc=3, R=4)):
+        pc = _product(cfg)
+        for a, b in zip(pc.bounds(), LR.bounds(cfg)):
+            np.testing.assert_array_equal(a, b)                      # two independent statements of V4:158-176
+        s = nmpc_amd.LidarSolver(pc, max_batch=9)
+        B = 9
+        P = rng.normal(size=(B, cfg.n_p)); W = rng.normal(size=(B, cfg.n_var)); W[:, 3: 3 + cfg.R] = np.abs(W[:, 3: 3 + cfg.R]) + 0.3
+        W[:, : cfg.ns * (cfg.N + 1)].reshape(B, cfg.N + 1, cfg.ns)[:, :, 3:] = rng.uniform(0.3, 3.0, (B, cfg.N + 1, cfg.R))
+        f, g = s.eval_batch(P, W); torch.cuda.synchronize()
+        fo, go = O.lidar_eval_batch(cfg, P, W)
+        gn = np.stack([LR.constraints(cfg, W[b], P[b]) for b in range(2)])
+        assert np.abs(go[:2] - gn).max() < 1e-12
+        assert np.abs(g.cpu().numpy() - go).max() <= 1e-12 * max(1.0, np.abs(go).max())
+        assert np.max(np.abs(f.cpu().numpy() - fo) / np.maximum(1.0, np.abs(fo))) < 1e-12
+        wn = s.shift_batch(W).cpu().numpy()
+        assert np.array_equal(wn, np.stack([LR.shift_guess(cfg, w) for w in W]))      # pure data movement: bit-exact
+
+
+@pytest.mark.parametrize("name,cfg,B", [("v4", LR.lidar_v4(), 96), ("v3", LR.lidar_v3(), 24), ("v4_aligned", LR.LidarConfig(aligned_bounds=True), 64),
+                                        ("short", LR.LidarConfig(N=12, Nc=6, R=4, aligned_bounds=True), 130)])
+def test_lidar_solve_matches_oracle(built, name, cfg, B):
+    import torch
+    import nmpc_amd
+    P, W0 = _batch(cfg, B, 11)
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    s = nmpc_amd.LidarSolver(_product(cfg, max_iter=1500), lbx=lbx, ubx=ubx, max_batch=B)
+    r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.lidar_solve_batch(cfg, P, W0, max_iter=1500)
+    print(f"{name}: status hip {np.bincount(r['status'], minlength=5)} oracle {np.bincount(ref['status'], minlength=5)}, iters hip mean {r['iters'].mean():.1f} max {r['iters'].max()} "
+          f"oracle mean {ref['iters'].mean():.1f}")
+    assert (r["status"] == ref["status"]).all(), (r["status"], ref["status"])
+    conv = r["status"] == 0
+    assert conv.mean() >= 0.9, r["status"]
+    assert (r["kkt"][conv] <= 1e-8).all()
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    assert (dw[conv] <= W_TOL).mean() >= 0.97, dw
+    same = conv & (dw <= W_TOL)
+    assert (np.abs(r["f"] - ref["f"])[same] <= 1e-6 * np.maximum(1.0, np.abs(ref["f"][same]))).all()
+    assert (r["iters"] == ref["iters"])[conv].mean() >= 0.9
+    for b in np.where(conv)[0][:6]:
+        k = LR.kkt_report(cfg, r["x"][b], P[b], tol_active=1e-4)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, (b, k)
+    # X_0 pinned; the caller's bounds hold entry by entry
+    assert np.array_equal(r["x"][:, :3], P[:, :3]) and np.array_equal(r["x"][:, 3: 3 + cfg.R], P[:, 6: 6 + cfg.R])
+    assert (r["x"][conv] >= lbx - 1e-12).all() and (r["x"][conv] <= ubx + 1e-12).all()
+
+
+def test_lidar_reference_call_surface_and_closed_loop(built):
+    """the loop of V4:209-300 with a synthetic scan: p = [x0; xs; scan; B0], the keyword call with the script's own bounds arrays,
+    u = first control, shift of the guess; 6 control periods with the plant x0 + T f(x0, u0) standing in for the robot."""
+    import nmpc_amd
+    cfg = nmpc_amd.lidar_v4()
+    ocfg = LR.lidar_v4()
+    opts = {'print_time': 0, 'ipopt': {'max_iter': 2000, 'print_level': 0, 'acceptable_tol': 1e-8, 'acceptable_obj_change_tol': 1e-6}}
+    lbx, ubx, lbg, ubg = cfg.bounds()
+    solver = nmpc_amd.lidar_nlpsol('solver', 'ipopt', cfg, opts, lbx=lbx, ubx=ubx)
+    obst = [(1.2, 0.9, 0.25), (2.0, 2.2, 0.3)]
+    pose = np.array([0.0, 0.0, 0.0]); xs = np.array([3.0, 2.5, 0.0])
+    scan = LR.scan_of_world(pose, obst, cfg.R)
+    x0 = np.concatenate([pose, scan])
+    w = nmpc_amd.lidar_cold_start(cfg, x0)
+    ns, N, Nc = cfg.ns, cfg.N, cfg.Nc
+    d0 = np.linalg.norm(pose[:2] - xs[:2])
+    for it in range(6):
+        p = nmpc_amd.lidar_params(cfg, pose, xs, scan)
+        sol = solver(x0=w.reshape(-1, 1), p=p.reshape(-1, 1), lbx=lbx.reshape(-1, 1), ubx=ubx.reshape(-1, 1), lbg=lbg.reshape(1, -1), ubg=ubg.reshape(1, -1))
+        assert solver.stats()['success'], solver.stats()
+        assert sol['x'].shape == (cfg.n_var, 1) and sol['g'].shape == (cfg.n_g, 1) and np.abs(sol['g']).max() < 1e-8
+        assert abs(sol['f'] - LR.objective(ocfg, sol['x'], p)) < 1e-9 * max(1.0, abs(sol['f']))
+        u = sol['x'][ns * (N + 1):].reshape(Nc, 2)
+        assert (np.abs(u[:, 0]) <= cfg.v_max + 1e-12).all() and (np.abs(u[:, 1]) <= cfg.w_max + 1e-12).all()
+        pose = pose + cfg.T * np.array([u[0, 0] * np.cos(pose[2]), u[0, 0] * np.sin(pose[2]), u[0, 1]])
+        scan = LR.scan_of_world(pose, obst, cfg.R)
+        w = solver.shift_batch(sol['x'].reshape(1, -1)).cpu().numpy()[0]
+        assert np.array_equal(w, LR.shift_guess(ocfg, sol['x']))
+    assert np.linalg.norm(pose[:2] - xs[:2]) < d0
+    with pytest.raises(ValueError):
+        solver(x0=w, p=p, lbx=lbx * 2)
+
+
+def test_lidar_edge_cases(built):
+    import ctypes as C
+    import torch
+    import nmpc_amd
+    cfg = LR.LidarConfig(N=12, Nc=6, R=4, aligned_bounds=True)
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    s = nmpc_amd.LidarSolver(_product(cfg), lbx=lbx, ubx=ubx, max_batch=4)
+    r = s.solve_batch(np.zeros((0, cfg.n_p)), np.zeros((0, cfg.n_var)))
+    assert r["x"].shape == (0, cfg.n_var)
+    P, W0 = _batch(cfg, 8, 5)
+    with pytest.raises(ValueError):
+        s.solve_batch(P, W0)
+    # a scan below the lower bound of the (pinned) stage-0 distance states: status 3, guess returned (with X_0 pinned)
+    P2 = P[:2].copy(); P2[0, 6] = 0.05
+    W2 = W0[:2].copy()
+    r2 = _np(s.solve_batch(P2, W2)); ref2 = O.lidar_solve_batch(cfg, P2, W2)
+    assert r2["status"][0] == 3 and ref2["status"][0] == 3 and r2["status"][1] == ref2["status"][1] == 0
+    # iteration limit 0
+    s0 = nmpc_amd.LidarSolver(_product(cfg, max_iter=0), lbx=lbx, ubx=ubx, max_batch=4)
+    r0 = _np(s0.solve_batch(P[:4], W0[:4])); ref0 = O.lidar_solve_batch(cfg, P[:4], W0[:4], max_iter=0)
+    assert (r0["status"] == 1).all() and (r0["iters"] == 0).all() and np.abs(r0["x"] - ref0["x"]).max() <= 1e-15
+    # bad bounds / configs are rejected by the C ABI
+    L = nmpc_amd._lib.load(); h = C.c_void_p(); dp = C.POINTER(C.c_double)
+    cc = _product(cfg).to_c()
+    bad = lbx.copy(); bad[20] = ubx[20] + 1.0
+    assert L.nmpc_lidar_create(C.byref(cc), bad.ctypes.data_as(dp), ubx.ctypes.data_as(dp), 4, C.byref(h)) == -1
+    c2 = _product(cfg); c2.Nc = cfg.N + 1
+    assert L.nmpc_lidar_create(C.byref(c2.to_c()), lbx.ctypes.data_as(dp), ubx.ctypes.data_as(dp), 4, C.byref(h)) == -1
+    assert L.nmpc_lidar_n_var(None) == -1

@@ -1,0 +1,92 @@
+"""CPU: the LIDAR-ray distance-state NMPC oracle pinned by what the reference text fixes
+(V4 = AllScripts/obs_avoid_static_first_scenario_v4.py, V3 = ..._v3.py): layout, cold-start values, bounds as built,
+finite-difference derivatives, the least-squares KKT report and scipy-SLSQP on a small instance ("scipy-SLSQP, not CasADi/IPOPT")."""
+import numpy as np
+import pytest
+
+from oracle import lidar_ref as LR, oracle_lib as O
+
+OBST = [(1.2, 0.9, 0.25), (2.0, 2.2, 0.3), (0.8, -0.6, 0.2)]
+
+
+def _instance(cfg, pose, xs):
+    scan = LR.scan_of_world(pose, OBST, cfg.R)
+    return LR.make_p(cfg, pose, xs, scan), LR.cold_start(cfg, np.concatenate([pose, scan]))
+
+
+def test_layout_and_bounds_as_the_script_builds_them():
+    cfg = LR.lidar_v4()
+    assert (cfg.ns, cfg.n_var, cfg.n_g, cfg.n_p) == (13, 13 * 101 + 2 * 50, 13 * 101, 26)        # 1413 / 1313
+    lbx, ubx, lbg, ubg = LR.bounds(cfg)
+    assert lbx.shape == (1413,) and not lbg.any() and not ubg.any()                                # all rows are equalities (V4:158-159)
+    # V4:161-172: pose pattern for the first 3(N+1) = 303 entries, distance bounds for the remaining 1010 of the state part
+    assert np.array_equal(lbx[:6], [-10, -10, -np.inf, -10, -10, -np.inf]) and (lbx[303:1313] == 0.15).all() and (ubx[303:1313] == 10.0).all()
+    assert np.array_equal(lbx[1313:1317], [-0.15, -1.5, -0.15, -1.5])
+    # consequence of the misalignment, reproduced: from stage 24 on the POSE entries of w carry the distance bounds [0.15, 10]
+    assert lbx[24 * 13] == 0.15 and lbx[24 * 13 + 2] == 0.15 and lbx[23 * 13] == -np.inf and lbx[23 * 13 + 1] == -10.0      # 299 % 3 == 2: the theta pattern
+    c3 = LR.lidar_v3()
+    assert (c3.N, c3.Nc, c3.lw, c3.n_var) == (125, 125, 0.0, 13 * 126 + 2 * 125)
+    # rows: all gx then all gd (V4:151); cold start (V4:184-196): defects and distance rows vanish except the distance rows of
+    # the stages, which equal scan - ||p0 - pObs||_1 with pObs one scan length away along each ray
+    pose = np.array([0.2, -0.1, 0.3]); xs = np.array([3.0, 2.5, 0.0])
+    p, w0 = _instance(cfg, pose, xs)
+    g = LR.constraints(cfg, w0, p)
+    assert np.abs(g[: 3 * 101]).max() == 0.0 and np.abs(g[3 * 101: 3 * 101 + 10]).max() == 0.0
+    B = LR.ray_angles(10); scan = p[6:16]
+    want = scan - scan * (np.abs(np.cos(pose[2] + B)) + np.abs(np.sin(pose[2] + B)))
+    assert np.abs(g[3 * 101 + 10: 3 * 101 + 20] - want).max() < 1e-14
+    f0 = LR.objective(cfg, w0, p)
+    assert f0 == pytest.approx(100 * (np.dot(cfg.q, (pose - xs) ** 2) + 0.1 * np.sum(1.0 / scan ** 2)), rel=1e-13)
+    # shift (V4:258-270): row N-1 appended, controls drop first / repeat last
+    X, U = LR.unpack(cfg, np.arange(cfg.n_var, dtype=float))
+    Xs, Us = LR.unpack(cfg, LR.shift_guess(cfg, np.arange(cfg.n_var, dtype=float)))
+    assert np.array_equal(Xs[:-1], X[1:]) and np.array_equal(Xs[-1], X[cfg.N - 1]) and np.array_equal(Us[:-1], U[1:]) and np.array_equal(Us[-1], U[-1])
+
+
+def test_derivatives_and_c_evaluation():
+    cfg = LR.LidarConfig(N=8, Nc=4, R=4, aligned_bounds=True)
+    pose = np.array([0.0, 0.0, 0.1]); xs = np.array([1.5, 0.8, 0.0])
+    p, w0 = _instance(cfg, pose, xs)
+    rng = np.random.default_rng(0)
+    w = w0 + 0.05 * rng.normal(size=w0.size); w[3: 3 + cfg.R] = np.abs(w[3: 3 + cfg.R]) + 0.5
+    J = LR.jacobian(cfg, w, p); gf = LR.grad_objective(cfg, w, p)
+    h = 1e-6
+    for i in range(w.size):
+        e = np.zeros(w.size); e[i] = h
+        assert np.abs((LR.constraints(cfg, w + e, p) - LR.constraints(cfg, w - e, p)) / (2 * h) - J[:, i]).max() < 1e-7, i
+        assert abs((LR.objective(cfg, w + e, p) - LR.objective(cfg, w - e, p)) / (2 * h) - gf[i]) < 1e-6, i
+    f, g = O.lidar_eval_batch(cfg, p[None], w[None])
+    assert abs(f[0] - LR.objective(cfg, w, p)) < 1e-12 and np.abs(g[0] - LR.constraints(cfg, w, p)).max() < 1e-14
+
+
+@pytest.mark.parametrize("name,cfg", [("v4", LR.lidar_v4()), ("v3", LR.lidar_v3()), ("v4_aligned", LR.LidarConfig(aligned_bounds=True)),
+                                      ("small", LR.LidarConfig(N=12, Nc=6, R=4, aligned_bounds=True))])
+def test_oracle_solutions_are_kkt_points(name, cfg):
+    """the solve against the solver-independent KKT report (least-squares multipliers on the active set, full-space Jacobian
+    including the dependence of the lidar points on the stage-0 variables)."""
+    pose = np.array([0.0, 0.0, 0.0]); xs = np.array([3.0, 2.5, 0.0])
+    p, w0 = _instance(cfg, pose, xs)
+    r = O.lidar_solve_batch(cfg, p[None], w0[None], max_iter=1500)
+    assert r["status"][0] == 0 and r["kkt"][0] <= 1e-8, (r["status"], r["iters"], r["kkt"])
+    k = LR.kkt_report(cfg, r["x"][0], p, tol_active=1e-4)
+    assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, k
+    X, U = LR.unpack(cfg, r["x"][0])
+    assert np.array_equal(X[0, :3], pose) and np.array_equal(X[0, 3:], p[6: 6 + cfg.R])              # X_0 pinned
+    if name == "v4":       # the misaligned bounds are active: the pose of stage 24 sits on its "distance" bound 0.15
+        assert abs(X[24, 0] - 0.15) < 1e-6
+
+
+def test_oracle_matches_slsqp_small():
+    """an INDEPENDENT solver (scipy SLSQP) on the restated NLP, small enough for its dense algebra."""
+    from scipy.optimize import Bounds, minimize
+    cfg = LR.LidarConfig(N=10, Nc=5, R=3, aligned_bounds=True)
+    for pose, xs in ((np.array([0.0, 0.0, 0.1]), np.array([1.5, 0.8, 0.0])), (np.array([0.3, -0.2, 1.0]), np.array([-1.0, 0.5, 0.5]))):
+        p, w0 = _instance(cfg, pose, xs)
+        lbx, ubx, _, _ = LR.bounds(cfg)
+        res = minimize(lambda w: LR.objective(cfg, w, p), w0, jac=lambda w: LR.grad_objective(cfg, w, p), bounds=Bounds(lbx, ubx),
+                       constraints=[{"type": "eq", "fun": lambda w: LR.constraints(cfg, w, p), "jac": lambda w: LR.jacobian(cfg, w, p)}],
+                       method="SLSQP", options={"ftol": 1e-14, "maxiter": 500})
+        r = O.lidar_solve_batch(cfg, p[None], w0[None], max_iter=500)
+        assert r["status"][0] == 0
+        assert abs(r["f"][0] - res.fun) <= 1e-6 * max(1.0, abs(res.fun)), (r["f"][0], res.fun)
+        assert np.abs(r["x"][0] - res.x).max() < 2e-4
