@@ -312,6 +312,41 @@ def main():
                                  "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version)})
             del s2
             torch.cuda.empty_cache()
+    # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
+    # 13 states, N=100, Nc=50; SURVEY.md 0 mismatch 2): one lane per instance, the workspace streams through HBM
+    if world == 1 and do_sweep:
+        from oracle import lidar_ref as LR
+        lc = LR.lidar_v4()
+        Bl = 4096
+        rngl = np.random.Generator(np.random.PCG64(Hh.SEED0 + 5))
+        Pl, Wl = [], []
+        for _ in range(Bl):
+            pose = np.array([rngl.uniform(0.0, 0.15), rngl.uniform(0.0, 0.15), rngl.uniform(0.4, 1.1)])
+            world_ = [(float(rngl.uniform(0.8, 2.6)), float(rngl.uniform(0.3, 2.4)), float(rngl.uniform(0.15, 0.3))) for _ in range(3)]
+            scan = LR.scan_of_world(pose, world_, lc.R)
+            Pl.append(LR.make_p(lc, pose, np.array([3.0, 2.5, 0.0]) + rngl.uniform(-0.3, 0.3, 3), scan)); Wl.append(LR.cold_start(lc, np.concatenate([pose, scan])))
+        Pl = np.stack(Pl); Wl = np.stack(Wl)
+        lbx, ubx, _, _ = LR.bounds(lc)
+        ls = nmpc_amd.LidarSolver(nmpc_amd.lidar_v4(), lbx=lbx, ubx=ubx, max_batch=Bl)
+        dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
+        itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
+        alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
+        # per iteration the lane-per-instance kernel reads or writes its structure-of-arrays workspace a fixed number of times;
+        # the model below counts those passes (doubles per instance and iteration) from the kernel source
+        nV = (lc.N + 1) * lc.ns
+        ws_doubles_per_iter = 30.0 * nV          # ~30 passes over state-sized arrays (V, slacks, duals, step, trial point) per iteration incl. 1.3 merit evaluations
+        out["sweep"].append({"workload": "lidar_v4: 1 robot, 13 states (pose + 10 ray distances), N=100, Nc=50, batch=%d, cold start" % Bl,
+                             "m": 1, "N": lc.N, "batch": Bl, "value": Bl * 2 / dl, "unit": "solves/s", "ms_per_step": 1e3 * dl / 2,
+                             "mean_iters": float(itl.mean()), "max_iters": float(itl.max()), "converged_frac": float((stl == 0).mean()),
+                             "status_counts": {str(k): int((stl == k).sum()) for k in np.unique(stl)},
+                             "roofline": {"bound": "hbm", "kernel": "nmpc_lidar::lidar_solve_kernel", "kernel_ms": kl,
+                                          "achieved": ws_doubles_per_iter * 8.0 * float(itl.sum()) / (kl * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": ws_doubles_per_iter * 8.0 * float(itl.sum()) / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                          "algorithmic_bytes_per_launch": alg_bytes,
+                                          "note": "achieved = modelled workspace traffic (30 state-sized array passes per iteration x iterations), not PMC; "
+                                                  "the kernel is latency-bound: 64 independent serial solves per wavefront"}})
+        del ls
+        torch.cuda.empty_cache()
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)
     # CPU baseline: the C oracle on this box's host cores, bounded sample of the same workload
     if world == 1 and args.cpu_sample != 0:

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                                                           double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
                                                           int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;      // blockDim.x = instances per wavefront (1..64), see nmpc_lidar_solve_batch
     if (b >= B) return;
     const int N = P.N, Nc = P.Nc, R = P.R, ns = P.ns;
     const size_t S = (size_t)P.S;
@@ -619,7 +619,14 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
+    // Instances per wavefront.  Every lane runs a serial solve whose inner loops wait on HBM (the iterate does not fit on chip:
+    // ~100 KB per instance), so the kernel is bound by memory LATENCY times the length of one solve, and what hides latency is the
+    // number of wavefronts in flight, not the lanes per wavefront: the batch is spread over ~4 wavefronts per SIMD (4096 on the
+    // chip) before lanes are filled up.  NMPC_LIDAR_LANES overrides (development).
+    int lanes = (B + 4095) / 4096;
+    if (const char *e = getenv("NMPC_LIDAR_LANES")) lanes = atoi(e);
+    lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)((B + lanes - 1) / lanes)), dim3(lanes), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
