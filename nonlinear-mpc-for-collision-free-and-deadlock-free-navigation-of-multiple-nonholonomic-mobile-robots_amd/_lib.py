@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libnmpc_hip.so")
+SO_PATH = os.environ.get("NMPC_SO") or os.path.join(HERE, "libnmpc_hip.so")      # NMPC_SO: development (A/B builds in one GPU session)
 
 NMPC_MAX_ROBOTS = 10
 NMPC_MAX_OBSTACLES = 8

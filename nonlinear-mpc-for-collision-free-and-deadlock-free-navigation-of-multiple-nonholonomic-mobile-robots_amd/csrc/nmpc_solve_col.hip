@@ -25,6 +25,11 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// rows below this index fetch their elimination multiplier with v_readlane, the others from the LDS broadcast of the pivot row
+#ifndef NMPC_RL_SPLIT
+#define NMPC_RL_SPLIT(NU_, NZ_) (NZ_)
+#endif
+
 // lane that owns column c of the augmented matrix: state column NU + s on lane s, control column a on lane 32 + a
 #define LC(c) (((c) < NU) ? 32 + (c) : (c) - NU)
 
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     constexpr int RG0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     double *XS = RV + ((N1 * NX > RG0) ? N1 * NX : RG0);   // [NX]
     double *RED = XS + NX;                // [8]
-    double *BR = RED + 8;                 // [2][64]  pivot row of the current / previous pivot step, one entry per lane (multiplier broadcast)
+    double *BR = RED + 8;                 // [2][64]  (only when NMPC_RL_SPLIT < NZ) pivot row of the current / previous pivot step, one entry per lane
     double *gd = ws + inst * P.stride2 + P.oDUAL;
     double *SPp = gd;                     // [N1*NP]   pair slacks
     double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
@@ -595,22 +600,28 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                         const double inv = inv_cur;
                         if (!(inv > 0.0)) ok = false;
                         else {
+                            // multipliers M[j][a], a > j: rows a < RL_SPLIT through v_readlane (2 VALU instructions each, the SIMD's own
+                            // pipe), rows a >= RL_SPLIT through one LDS broadcast of the pivot row (uniform-address ds_read_b128, two rows
+                            // each, the pipe the four SIMDs of a CU share): the split balances the two pipes at full occupancy
+                            constexpr int RL_SPLIT = NMPC_RL_SPLIT(NU, NZ);
                             double *br = BR + (j & 1) * 64;
-                            br[tid] = m[j];
+                            if constexpr (RL_SPLIT < NZ) br[tid] = m[j];
                             if (lvalid) gkt[(size_t)k * G::KTS + j * LD + mycol] = m[j];      // pivot row j as the forward sweep reads it
                             const double rhs_j = lane_read(m[NZ], LC(j));
                             invv = (tid == j) ? inv : invv; rhsv = (tid == j) ? rhs_j : rhsv;
                             const double rjv = m[j] * inv;
-                            lds_sync<TPB>();
-                            double sm_[NZ];                  // multipliers of the remaining rows (wave-uniform values in VGPRs)
-                            static_for<j + 1, NZ>([&](auto ac) { constexpr int a = decltype(ac)::value; sm_[a] = br[LC(a)]; });
+                            if constexpr (RL_SPLIT < NZ) lds_sync<TPB>();
+                            auto mult = [&](auto ac) {
+                                constexpr int a = decltype(ac)::value;
+                                if constexpr (a < RL_SPLIT) return lane_read(m[j], LC(a)); else return br[LC(a)];
+                            };
                             if constexpr (j + 1 < NU) {       // the next pivot row first: its reciprocal overlaps the other rows
-                                m[j + 1] = fma(-sm_[j + 1], rjv, m[j + 1]);
+                                m[j + 1] = fma(-mult(std::integral_constant<int, j + 1>{}), rjv, m[j + 1]);
                                 inv_cur = pivot_inv(lane_read(m[j + 1], LC(j + 1)), d0s[j + 1]);
                             }
                             static_for<(j + 1 < NU ? j + 2 : j + 1), NZ>([&](auto ac) {
                                 constexpr int a = decltype(ac)::value;
-                                m[a] = fma(-sm_[a], rjv, m[a]);
+                                m[a] = fma(-mult(ac), rjv, m[a]);
                             });
                             m[NZ] = fma(-rhs_j, rjv, m[NZ]);
                         }
@@ -966,7 +977,7 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P)
     (void)MK;
     const size_t rg0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     d += (N1 * G::NX > rg0) ? N1 * G::NX : rg0;
-    d += G::NX + 8 + 128;
+    d += G::NX + 8 + (NMPC_RL_SPLIT(G::NU, G::NZ) < G::NZ ? 128 : 0);
     return d * sizeof(double);
 }
 
