@@ -313,7 +313,7 @@ def main():
             del s2
             torch.cuda.empty_cache()
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
-    # 13 states, N=100, Nc=50; SURVEY.md 0 mismatch 2): one lane per instance, the workspace streams through HBM
+    # 13 states, N=100, Nc=50; SURVEY.md 0 mismatch 2): one wavefront per instance, the instance's workspace lives in HBM/L2
     if world == 1 and do_sweep:
         from oracle import lidar_ref as LR
         lc = LR.lidar_v4()
@@ -331,7 +331,7 @@ def main():
         dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
         itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
         alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
-        # per iteration the lane-per-instance kernel reads or writes its structure-of-arrays workspace a fixed number of times;
+        # per iteration the kernel reads or writes the state-sized arrays of its workspace a fixed number of times;
         # the model below counts those passes (doubles per instance and iteration) from the kernel source
         nV = (lc.N + 1) * lc.ns
         ws_doubles_per_iter = 30.0 * nV          # ~30 passes over state-sized arrays (V, slacks, duals, step, trial point) per iteration incl. 1.3 merit evaluations
@@ -344,7 +344,7 @@ def main():
                                           "frac": ws_doubles_per_iter * 8.0 * float(itl.sum()) / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                           "algorithmic_bytes_per_launch": alg_bytes,
                                           "note": "achieved = modelled workspace traffic (30 state-sized array passes per iteration x iterations), not PMC; "
-                                                  "the kernel is latency-bound: 64 independent serial solves per wavefront"}})
+                                                  "the kernel is latency-bound (two serial recursions over 100 stages per iteration), not bandwidth-bound"}})
         del ls
         torch.cuda.empty_cache()
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)

@@ -6,12 +6,14 @@
 //
 // Mapping.  This NLP has ONE robot: the pose block is 3 x 3, the control block 2 x 2, and the R distance states of a stage are
 // eliminated through their own linearised equality rows (d = ||p - pObs||_1), so the Newton system is a 3-state Riccati
-// recursion whose matrices (5 x 5 with the held control of the move-blocked stages) fit the registers of ONE LANE.  One lane
-// therefore solves one instance (64 instances per wavefront, no cross-lane traffic at all) and the batch supplies the
-// parallelism; the iterate (13 x 101 states, slacks and duals of every bounded variable, multipliers, step) lives in the
-// instance's workspace in HBM in structure-of-arrays order — element e of instance b at ws[e * S + b] — so that every access of a
-// wavefront is one coalesced 512-byte segment.  Algorithm: the interior-point iteration of nmpc_kernels.hip / the oracle
-// (barrier rule, fraction to the boundary, non-monotone l1-merit search, inertia shift on the control diagonal, barrier restart).
+// recursion whose matrices (5 x 5 with the held control of the move-blocked stages) fit the registers of one lane.  One
+// WAVEFRONT solves one instance: the phases that are parallel over the horizon (evaluation, optimality error, condensed stage
+// blocks, step lengths, merit function, update: ~95 % of the memory accesses) give every lane its own stages / variables of the
+// instance's contiguous workspace in HBM/L2 (coalesced, wave reductions with v_readfirstlane so that every decision is a scalar
+// branch), and the two recursions over the horizon run uniformly on all lanes with lane 0 storing.  (A first version gave every
+// LANE its own instance: 64 serial solves per wavefront whose every access waited on HBM, 0.5 k solves/s — slower than the CPU.)
+// Algorithm: the interior-point iteration of nmpc_kernels.hip / the oracle (barrier rule, fraction to the boundary, non-monotone
+// l1-merit search, inertia shift on the control diagonal, barrier restart).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -26,13 +28,13 @@ struct LParams {
     int32_t N, Nc, R, ns, max_iter, nvar, ng, np;
     double T, q[3], r[2], lw, tol, mu_init;
     const double *lb, *ub;      // device copies of the caller's lbx / ubx [n_var]
-    int64_t S;                  // instance stride of the structure-of-arrays workspace (batch rounded up to 64)
+    int64_t S;                  // instances the workspace holds (each `total` doubles, contiguous)
     // element offsets of the per-instance arrays
     int64_t oV, oU, olam, oeta, oSL, oZL, oSU, oZU, oSLu, oZLu, oSUu, oZUu, odV, odU, olamn, oetan, oVt, oUt, osn, ocs, oHxx, ogx, oWd,
         ogdv, ohuu, ogu, ohvt, oKg, okff, opo, total;
 };
 
-#define W_(off, i) ws[((size_t)(off) + (size_t)(i)) * S + b]
+#define W_(off, i) wsb[(off) + (i)]
 
 __device__ __forceinline__ double sgn(double a) { return (double)((a > 0.0) - (a < 0.0)); }
 
@@ -48,20 +50,34 @@ __device__ __forceinline__ double push_in(double v, double lo, double hi)
     return v;
 }
 
+// wave reductions whose result the compiler knows to be uniform (scalar control flow)
+__device__ __forceinline__ double uni(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double wsum_(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return uni(v); }
+__device__ __forceinline__ double wmax_(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return uni(v); }
+__device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return uni(v); }
+
+// One wavefront per instance.  The stage-parallel phases (evaluation, optimality error, condensed blocks, step lengths, merit,
+// update) spread stages / variables over the 64 lanes (coalesced accesses of the instance's contiguous workspace, wave
+// reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
+// recursion) run uniformly on all lanes, lane 0 storing.
 __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                           double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
                                                           int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;      // blockDim.x = instances per wavefront (1..64), see nmpc_lidar_solve_batch
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
     const int N = P.N, Nc = P.Nc, R = P.R, ns = P.ns;
-    const size_t S = (size_t)P.S;
     const double T = P.T;
+    double *wsb = ws + (size_t)b * (size_t)P.total;
     const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
     double *wo = w_out + (size_t)b * P.nvar;
     const double *lbv = P.lb, *ubv = P.ub, *lbu = P.lb + (size_t)(N + 1) * ns, *ubu = P.ub + (size_t)(N + 1) * ns;
     int64_t oV = P.oV, oVt = P.oVt, oU = P.oU, oUt = P.oUt;
     const double xs0 = pp[3], xs1 = pp[4], xs2 = pp[5];
+    const int nV = (N + 1) * ns;
     auto cof = [&](int k) { return k < Nc - 1 ? k : Nc - 1; };
     auto gdist = [&](int m, double x, double y, double &sx, double &sy) {
         double ax = x - W_(P.opo, 2 * m), ay = y - W_(P.opo, 2 * m + 1);
@@ -69,35 +85,36 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
         return fabs(ax) + fabs(ay);
     };
     // ---- load the start; X_0 (pose and scan) pinned to the parameters (V4:110-111); lidar points (V4:114-118)
-    for (int e = 0; e < (N + 1) * ns; e++) W_(oV, e) = wi[e];
-    for (int e = 0; e < 2 * Nc; e++) W_(oU, e) = wi[(size_t)(N + 1) * ns + e];
-    for (int i = 0; i < 3; i++) W_(oV, i) = pp[i];
-    for (int m = 0; m < R; m++) {
-        W_(oV, 3 + m) = pp[6 + m];
+    for (int e = lane; e < nV; e += 64) W_(oV, e) = (e < 3) ? pp[e] : ((e < ns) ? pp[6 + (e - 3)] : wi[e]);
+    for (int e = lane; e < 2 * Nc; e += 64) W_(oU, e) = wi[(size_t)nV + e];
+    for (int m = lane; m < R; m += 64) {
         double a = pp[2] + pp[6 + R + m], s, c;
         sincos(a, &s, &c);
         W_(P.opo, 2 * m) = pp[0] + pp[6 + m] * c; W_(P.opo, 2 * m + 1) = pp[1] + pp[6 + m] * s;
     }
+    __syncthreads();
     {   // the pinned stage-0 variables must respect their own bounds
-        bool bad = false;
-        for (int c = 0; c < ns; c++) { double v = W_(oV, c); if (v < lbv[c] || v > ubv[c]) bad = true; }
-        if (bad) {
-            for (int e = 0; e < (N + 1) * ns; e++) wo[e] = W_(oV, e);
-            for (int e = 0; e < 2 * Nc; e++) wo[(size_t)(N + 1) * ns + e] = W_(oU, e);
-            if (obj_out) obj_out[b] = NAN;
-            if (status_out) status_out[b] = NMPC_STATUS_INFEASIBLE_X0;
-            if (iters_out) iters_out[b] = 0;
-            if (kkt_out) kkt_out[b] = INFINITY;
+        double bad = 0.0;
+        for (int c = lane; c < ns; c += 64) { double v = W_(oV, c); if (v < lbv[c] || v > ubv[c]) bad = 1.0; }
+        if (wmax_(bad) > 0.0) {
+            for (int e = lane; e < nV; e += 64) wo[e] = W_(oV, e);
+            for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)nV + e] = W_(oU, e);
+            if (lane == 0) {
+                if (obj_out) obj_out[b] = NAN;
+                if (status_out) status_out[b] = NMPC_STATUS_INFEASIBLE_X0;
+                if (iters_out) iters_out[b] = 0;
+                if (kkt_out) kkt_out[b] = INFINITY;
+            }
             return;
         }
     }
-    int n_ineq = 4 * Nc;
-    for (int e = ns; e < (N + 1) * ns; e++) n_ineq += (isfinite(lbv[e]) ? 1 : 0) + (isfinite(ubv[e]) ? 1 : 0);
+    int n_ineq;
+    { double c = 0.0; for (int e = ns + lane; e < nV; e += 64) c += (isfinite(lbv[e]) ? 1.0 : 0.0) + (isfinite(ubv[e]) ? 1.0 : 0.0); n_ineq = 4 * Nc + (int)wsum_(c); }
 
-    // objective, sum / max of the equality residuals at (oVx, oUx); optionally the trig cache
+    // objective, sum / max of the equality residuals at (oVx, oUx): one stage per lane; optionally the trig cache
     auto eval_point = [&](int64_t oVx, int64_t oUx, bool trig, double &th, double &ec) {
-        double f = 0.0; th = 0.0; ec = 0.0;
-        for (int k = 0; k < N; k++) {
+        double f = 0.0, t_ = 0.0, e_ = 0.0;
+        for (int k = lane; k < N; k += 64) {
             const int j = cof(k);
             const double x = W_(oVx, k * ns), y = W_(oVx, k * ns + 1), t = W_(oVx, k * ns + 2), u0 = W_(oUx, 2 * j), u1 = W_(oUx, 2 * j + 1);
             const double xn = W_(oVx, (k + 1) * ns), yn = W_(oVx, (k + 1) * ns + 1), tn = W_(oVx, (k + 1) * ns + 2);
@@ -105,16 +122,17 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             sincos(t, &s, &c);
             if (trig) { W_(P.osn, k) = s; W_(P.ocs, k) = c; }
             const double c0 = xn - (x + T * u0 * c), c1 = yn - (y + T * u0 * s), c2 = tn - (t + T * u1);
-            th += fabs(c0) + fabs(c1) + fabs(c2); ec = fmax(ec, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
+            t_ += fabs(c0) + fabs(c1) + fabs(c2); e_ = fmax(e_, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
             f += P.q[0] * (x - xs0) * (x - xs0); f += P.q[1] * (y - xs1) * (y - xs1); f += P.q[2] * (t - xs2) * (t - xs2);
             f += P.r[0] * u0 * u0 + P.r[1] * u1 * u1;
             for (int m = 0; m < R; m++) {
                 if (P.lw != 0.0) { double d = W_(oVx, k * ns + 3 + m); f += P.lw / (d * d); }
                 double sx, sy, e = W_(oVx, (k + 1) * ns + 3 + m) - gdist(m, xn, yn, sx, sy);
-                th += fabs(e); ec = fmax(ec, fabs(e));
+                t_ += fabs(e); e_ = fmax(e_, fabs(e));
             }
         }
-        return f;
+        th = wsum_(t_); ec = wmax_(e_);
+        return wsum_(f);
     };
 
     double mu = P.mu_init, f = 0.0, th0 = 0.0, e_c = 0.0;
@@ -125,70 +143,76 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
     int mcount = 0;
 
     for (;;) {      // (re)start of the barrier iteration
-        for (int e = ns; e < (N + 1) * ns; e++) W_(oV, e) = push_in(W_(oV, e), lbv[e], ubv[e]);
-        for (int e = 0; e < 2 * Nc; e++) W_(oU, e) = push_in(W_(oU, e), lbu[e], ubu[e]);
-        for (int e = ns; e < (N + 1) * ns; e++) {
-            const double lo = lbv[e], hi = ubv[e], v = W_(oV, e);
+        for (int e = ns + lane; e < nV; e += 64) {
+            const double lo = lbv[e], hi = ubv[e], v = push_in(W_(oV, e), lo, hi);
+            W_(oV, e) = v;
             const double sl = isfinite(lo) ? fmax(v - lo, 1e-12) : 1.0, su = isfinite(hi) ? fmax(hi - v, 1e-12) : 1.0;
             W_(P.oSL, e) = sl; W_(P.oZL, e) = isfinite(lo) ? mu / sl : 0.0;
             W_(P.oSU, e) = su; W_(P.oZU, e) = isfinite(hi) ? mu / su : 0.0;
         }
-        for (int e = 0; e < 2 * Nc; e++) {
-            const double u = W_(oU, e), sl = fmax(u - lbu[e], 1e-12), su = fmax(ubu[e] - u, 1e-12);
+        for (int e = lane; e < 2 * Nc; e += 64) {
+            const double u = push_in(W_(oU, e), lbu[e], ubu[e]), sl = fmax(u - lbu[e], 1e-12), su = fmax(ubu[e] - u, 1e-12);
+            W_(oU, e) = u;
             W_(P.oSLu, e) = sl; W_(P.oZLu, e) = mu / sl; W_(P.oSUu, e) = su; W_(P.oZUu, e) = mu / su;
         }
-        for (int e = 0; e < (N + 1) * 3; e++) W_(P.olam, e) = 0.0;
-        for (int e = 0; e < (N + 1) * R; e++) W_(P.oeta, e) = 0.0;
+        for (int e = lane; e < (N + 1) * 3; e += 64) W_(P.olam, e) = 0.0;
+        for (int e = lane; e < (N + 1) * R; e += 64) W_(P.oeta, e) = 0.0;
+        __syncthreads();
         f = eval_point(oV, oU, true, th0, e_c);
+        __syncthreads();
         delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false;
 
         for (;;) {
-            // ---- A. optimality error (IPOPT eq. 5)
-            double e_d = 0.0, e_h = 0.0, zsum = 0.0, lsum = 0.0, cmax = 0.0, cmin = INFINITY;
-            for (int k = 1; k <= N; k++) {
-                const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1), t = W_(oV, k * ns + 2);
-                double r0 = W_(P.olam, 3 * k), r1 = W_(P.olam, 3 * k + 1), r2 = W_(P.olam, 3 * k + 2);
-                lsum += fabs(r0) + fabs(r1) + fabs(r2);
-                if (k < N) {
-                    const double l0 = W_(P.olam, 3 * k + 3), l1 = W_(P.olam, 3 * k + 4), l2 = W_(P.olam, 3 * k + 5), u0 = W_(oU, 2 * cof(k));
-                    const double a = -T * u0 * W_(P.osn, k), bq = T * u0 * W_(P.ocs, k);
-                    r0 += 2 * P.q[0] * (x - xs0) - l0; r1 += 2 * P.q[1] * (y - xs1) - l1; r2 += 2 * P.q[2] * (t - xs2) - l2;
-                    r2 -= a * l0 + bq * l1;
-                }
-                for (int m = 0; m < R; m++) {
-                    double sx, sy; gdist(m, x, y, sx, sy);
-                    const double et = W_(P.oeta, k * R + m), d = W_(oV, k * ns + 3 + m);
-                    r0 -= et * sx; r1 -= et * sy;
-                    double rd = et + ((k < N && P.lw != 0.0) ? -2.0 * P.lw / (d * d * d) : 0.0);
-                    rd -= W_(P.oZL, k * ns + 3 + m) - W_(P.oZU, k * ns + 3 + m);
-                    e_d = fmax(e_d, fabs(rd)); lsum += fabs(et);
-                }
-                r0 -= W_(P.oZL, k * ns) - W_(P.oZU, k * ns); r1 -= W_(P.oZL, k * ns + 1) - W_(P.oZU, k * ns + 1); r2 -= W_(P.oZL, k * ns + 2) - W_(P.oZU, k * ns + 2);
-                e_d = fmax(e_d, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
-                for (int c = 0; c < ns; c++) {
-                    const int e = k * ns + c;
-                    const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
-                    if (isfinite(lo)) { double sl = W_(P.oSL, e), zl = W_(P.oZL, e), pz = sl * zl; zsum += zl; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((v - lo) - sl)); }
-                    if (isfinite(hi)) { double su = W_(P.oSU, e), zu = W_(P.oZU, e), pz = su * zu; zsum += zu; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((hi - v) - su)); }
-                }
-            }
-            for (int j = 0; j < Nc; j++) {
-                double ru0 = 0.0, ru1 = 0.0;
-                const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1);
-                for (int k = j; k < N; k++) {
-                    if (cof(k) != j) break;
-                    ru0 += 2 * P.r[0] * u0 - T * (W_(P.ocs, k) * W_(P.olam, 3 * k + 3) + W_(P.osn, k) * W_(P.olam, 3 * k + 4));
-                    ru1 += 2 * P.r[1] * u1 - T * W_(P.olam, 3 * k + 5);
-                }
+            // ---- A. optimality error (IPOPT eq. 5): one stage per lane
+            double e_d = 0.0, e_h = 0.0, zsum = 0.0, lsum = 0.0, cmax = 0.0, cmin = INFINITY, pu0 = 0.0, pu1 = 0.0;
+            auto ctrl_rows = [&](int j, double ru0, double ru1) {      // stationarity / complementarity of control j given its Lagrangian gradient
                 for (int e = 0; e < 2; e++) {
                     const int o = 2 * j + e;
-                    const double zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), sl = W_(P.oSLu, o), su = W_(P.oSUu, o), u = e ? u1 : u0;
+                    const double zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), sl = W_(P.oSLu, o), su = W_(P.oSUu, o), u = W_(oU, o);
                     const double ru = (e ? ru1 : ru0) - (zl - zu);
                     e_d = fmax(e_d, fabs(ru)); zsum += zl + zu;
                     cmax = fmax(cmax, fmax(sl * zl, su * zu)); cmin = fmin(cmin, fmin(sl * zl, su * zu));
                     e_h = fmax(e_h, fmax(fabs((u - lbu[o]) - sl), fabs((ubu[o] - u) - su)));
                 }
+            };
+            for (int k = lane; k <= N; k += 64) {
+                if (k >= 1) {
+                    const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1), t = W_(oV, k * ns + 2);
+                    double r0 = W_(P.olam, 3 * k), r1 = W_(P.olam, 3 * k + 1), r2 = W_(P.olam, 3 * k + 2);
+                    lsum += fabs(r0) + fabs(r1) + fabs(r2);
+                    if (k < N) {
+                        const double l0 = W_(P.olam, 3 * k + 3), l1 = W_(P.olam, 3 * k + 4), l2 = W_(P.olam, 3 * k + 5), u0 = W_(oU, 2 * cof(k));
+                        const double a = -T * u0 * W_(P.osn, k), bq = T * u0 * W_(P.ocs, k);
+                        r0 += 2 * P.q[0] * (x - xs0) - l0; r1 += 2 * P.q[1] * (y - xs1) - l1; r2 += 2 * P.q[2] * (t - xs2) - l2;
+                        r2 -= a * l0 + bq * l1;
+                    }
+                    for (int m = 0; m < R; m++) {
+                        double sx, sy; gdist(m, x, y, sx, sy);
+                        const double et = W_(P.oeta, k * R + m), d = W_(oV, k * ns + 3 + m);
+                        r0 -= et * sx; r1 -= et * sy;
+                        double rd = et + ((k < N && P.lw != 0.0) ? -2.0 * P.lw / (d * d * d) : 0.0);
+                        rd -= W_(P.oZL, k * ns + 3 + m) - W_(P.oZU, k * ns + 3 + m);
+                        e_d = fmax(e_d, fabs(rd)); lsum += fabs(et);
+                    }
+                    r0 -= W_(P.oZL, k * ns) - W_(P.oZU, k * ns); r1 -= W_(P.oZL, k * ns + 1) - W_(P.oZU, k * ns + 1); r2 -= W_(P.oZL, k * ns + 2) - W_(P.oZU, k * ns + 2);
+                    e_d = fmax(e_d, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
+                    for (int c = 0; c < ns; c++) {
+                        const int e = k * ns + c;
+                        const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
+                        if (isfinite(lo)) { double sl = W_(P.oSL, e), zl = W_(P.oZL, e), pz = sl * zl; zsum += zl; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((v - lo) - sl)); }
+                        if (isfinite(hi)) { double su = W_(P.oSU, e), zu = W_(P.oZU, e), pz = su * zu; zsum += zu; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((hi - v) - su)); }
+                    }
+                }
+                if (k < N) {       // control rows: stage k contributes to the Lagrangian gradient of control cof(k)
+                    const int j = cof(k);
+                    const double g0 = 2 * P.r[0] * W_(oU, 2 * j) - T * (W_(P.ocs, k) * W_(P.olam, 3 * k + 3) + W_(P.osn, k) * W_(P.olam, 3 * k + 4));
+                    const double g1 = 2 * P.r[1] * W_(oU, 2 * j + 1) - T * W_(P.olam, 3 * k + 5);
+                    if (k < Nc - 1) ctrl_rows(j, g0, g1); else { pu0 += g0; pu1 += g1; }
+                }
             }
+            pu0 = wsum_(pu0); pu1 = wsum_(pu1);
+            if (lane == 0) ctrl_rows(Nc - 1, pu0, pu1);       // the held control: the sum over its stages
+            e_d = wmax_(e_d); e_h = wmax_(e_h); zsum = wsum_(zsum); lsum = wsum_(lsum); cmax = wmax_(cmax); cmin = wmin_(cmin);
             const double smax = 100.0;
             const double s_d = fmax(smax, (lsum + zsum) / (double)(N * ns + n_ineq)) / smax;
             const double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
@@ -206,8 +230,8 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             }
             const double tau = fmax(0.99, 1.0 - mu);
 
-            // ---- B0. condensed stage blocks.  slot: v = mu/s - sigma (h - s), sigma = z/s
-            for (int k = 1; k <= N; k++) {
+            // ---- B0. condensed stage blocks, one stage per lane.  slot: v = mu/s - sigma (h - s), sigma = z/s
+            for (int k = 1 + lane; k <= N; k += 64) {
                 const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1);
                 double H0 = 0.0, H1 = 0.0, H2 = 0.0, hd[3] = {0, 0, 0}, g[3] = {0, 0, 0};
                 if (k < N) {
@@ -237,16 +261,17 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 W_(P.oHxx, 4 * k) = H0 + hd[0]; W_(P.oHxx, 4 * k + 1) = H1; W_(P.oHxx, 4 * k + 2) = H2 + hd[1]; W_(P.oHxx, 4 * k + 3) = H3;
                 W_(P.ogx, 3 * k) = g[0]; W_(P.ogx, 3 * k + 1) = g[1]; W_(P.ogx, 3 * k + 2) = g[2];
             }
-            for (int k = 0; k < N; k++) W_(P.ohvt, k) = T * (W_(P.olam, 3 * k + 3) * W_(P.osn, k) - W_(P.olam, 3 * k + 4) * W_(P.ocs, k));
-            for (int o = 0; o < 2 * Nc; o++) {
+            for (int k = lane; k < N; k += 64) W_(P.ohvt, k) = T * (W_(P.olam, 3 * k + 3) * W_(P.osn, k) - W_(P.olam, 3 * k + 4) * W_(P.ocs, k));
+            for (int o = lane; o < 2 * Nc; o += 64) {
                 const int j = o >> 1, e = o & 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
                 const double sl = W_(P.oSLu, o), su = W_(P.oSUu, o), zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), u = W_(oU, o);
                 W_(P.ohuu, o) = cnt * 2 * P.r[e] + zl / sl + zu / su;
                 const double vl = mu / sl - zl / sl * ((u - lbu[o]) - sl), vu = mu / su - zu / su * ((ubu[o] - u) - su);
                 W_(P.ogu, o) = cnt * 2 * P.r[e] * u - (vl - vu);
             }
+            __syncthreads();
 
-            // ---- B. Riccati sweep on z = (pose (3), held control (2)) with inertia correction; everything of a stage in registers
+            // ---- B. Riccati sweep on z = (pose (3), held control (2)) with inertia correction; uniform on all lanes, stage in registers
             double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
             int ntry = 0;
             bool ok;
@@ -290,9 +315,9 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                         Mx[18] += W_(P.ohuu, 2 * j) + delta; Mx[24] += W_(P.ohuu, 2 * j + 1) + delta;
                         mv[3] += W_(P.ogu, 2 * j); mv[4] += W_(P.ogu, 2 * j + 1);
                         const double dv = Mx[18];
-                        if (!(dv > 0.0)) { ok = false; break; }
+                        if (!(uni(dv) > 0.0)) { ok = false; break; }
                         const double l43 = Mx[23] / dv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
-                        if (!(d1 > 1e-9 * fabs(d1o)) || !(d1 > 0.0)) { ok = false; break; }
+                        if (!(uni(d1) > 1e-9 * fabs(uni(d1o))) || !(uni(d1) > 0.0)) { ok = false; break; }
                         double Kk[6], kk[2];
 #pragma unroll
                         for (int q_ = 0; q_ < 4; q_++) {
@@ -300,9 +325,11 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                             const double y4 = (r4 - l43 * r3) / d1, y3 = (r3 - Mx[19] * y4) / dv;
                             if (q_ < 3) { Kk[q_] = -y3; Kk[3 + q_] = -y4; } else { kk[0] = -y3; kk[1] = -y4; }
                         }
+                        if (lane == 0) {
 #pragma unroll
-                        for (int q_ = 0; q_ < 6; q_++) W_(P.oKg, 6 * j + q_) = Kk[q_];
-                        W_(P.okff, 2 * j) = kk[0]; W_(P.okff, 2 * j + 1) = kk[1];
+                            for (int q_ = 0; q_ < 6; q_++) W_(P.oKg, 6 * j + q_) = Kk[q_];
+                            W_(P.okff, 2 * j) = kk[0]; W_(P.okff, 2 * j + 1) = kk[1];
+                        }
                         double Pn[9], pn[3];
 #pragma unroll
                         for (int r_ = 0; r_ < 3; r_++) {
@@ -338,9 +365,10 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
             if (delta > 0.0) delta_last = delta;
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
+            __syncthreads();
 
-            // ---- C. forward sweep
-            for (int c = 0; c < ns; c++) W_(P.odV, c) = 0.0;
+            // ---- C. forward sweep: the pose recursion uniform on all lanes, the R distance states of a stage one per lane
+            for (int c = lane; c < ns; c += 64) W_(P.odV, c) = 0.0;
             {
                 double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
                 for (int k = 0; k < N; k++) {
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                     if (k <= Nc - 1) {
                         du0 = W_(P.okff, 2 * j) + W_(P.oKg, 6 * j) * dx0 + W_(P.oKg, 6 * j + 1) * dx1 + W_(P.oKg, 6 * j + 2) * dx2;
                         du1 = W_(P.okff, 2 * j + 1) + W_(P.oKg, 6 * j + 3) * dx0 + W_(P.oKg, 6 * j + 4) * dx1 + W_(P.oKg, 6 * j + 5) * dx2;
-                        W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1;
+                        if (lane == 0) { W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1; }
                     }
                     const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1), s = W_(P.osn, k), c = W_(P.ocs, k);
                     const double xn = W_(oV, (k + 1) * ns), yn = W_(oV, (k + 1) * ns + 1), tn = W_(oV, (k + 1) * ns + 2);
@@ -356,15 +384,16 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                     const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (yn - (W_(oV, k * ns + 1) + T * u0 * s));
                     const double n2 = dx2 + T * du1 - (tn - (W_(oV, k * ns + 2) + T * u1));
                     dx0 = n0; dx1 = n1; dx2 = n2;
-                    W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2;
-                    for (int m = 0; m < R; m++) {     // dd = G dx + (g - d) at stage k+1
+                    if (lane == 0) { W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2; }
+                    if (lane < R) {     // dd = G dx + (g - d) at stage k+1
                         double sx, sy;
-                        const double gg = gdist(m, xn, yn, sx, sy);
-                        W_(P.odV, (k + 1) * ns + 3 + m) = sx * n0 + sy * n1 + (gg - W_(oV, (k + 1) * ns + 3 + m));
+                        const double gg = gdist(lane, xn, yn, sx, sy);
+                        W_(P.odV, (k + 1) * ns + 3 + lane) = sx * n0 + sy * n1 + (gg - W_(oV, (k + 1) * ns + 3 + lane));
                     }
                 }
             }
-            // ---- multipliers of the QP: eta+ from the distance rows, lambda+ by the adjoint recursion
+            __syncthreads();
+            // ---- multipliers of the QP: lambda+ by the adjoint recursion (uniform), eta+ from the distance rows (one per lane)
             double mult_max = 0.0;
             {
                 double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
@@ -379,15 +408,17 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                         l2 += ln2 + (-T * u0 * W_(P.osn, k)) * ln0 + (T * u0 * W_(P.ocs, k)) * ln1 - W_(P.ohvt, k) * W_(P.odU, 2 * j);
                     }
                     ln0 = l0; ln1 = l1; ln2 = l2;
-                    W_(P.olamn, 3 * k) = l0; W_(P.olamn, 3 * k + 1) = l1; W_(P.olamn, 3 * k + 2) = l2;
+                    if (lane == 0) { W_(P.olamn, 3 * k) = l0; W_(P.olamn, 3 * k + 1) = l1; W_(P.olamn, 3 * k + 2) = l2; }
                     mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
-                    for (int m = 0; m < R; m++) {
-                        const double e = -(W_(P.ogdv, k * R + m) + W_(P.oWd, k * R + m) * W_(P.odV, k * ns + 3 + m));
-                        W_(P.oetan, k * R + m) = e; mult_max = fmax(mult_max, fabs(e));
-                    }
                 }
+                for (int e = R + lane; e < (N + 1) * R; e += 64) {
+                    const int k = e / R, m = e - k * R;
+                    const double v = -(W_(P.ogdv, e) + W_(P.oWd, e) * W_(P.odV, k * ns + 3 + m));
+                    W_(P.oetan, e) = v; mult_max = fmax(mult_max, fabs(v));
+                }
+                mult_max = wmax_(mult_max);
             }
-            // ---- D. fraction to the boundary; directional derivative of the barrier function
+            // ---- D. fraction to the boundary; directional derivative of the barrier function (one variable per lane)
             double a_p = 1.0, a_d = 1.0, dphi = 0.0, lgs = 0.0, thh = 0.0;
             auto slot = [&](double s_, double z_, double h_, double jd_) {
                 const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
@@ -395,23 +426,24 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 if (dz_ < 0.0) a_d = fmin(a_d, -tau * z_ / dz_);
                 dphi -= mu * ds_ / s_; lgs += log(s_); thh += fabs(h_ - s_);
             };
-            for (int e = ns; e < (N + 1) * ns; e++) {
+            for (int e = ns + lane; e < nV; e += 64) {
                 const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
                 if (isfinite(lo)) slot(W_(P.oSL, e), W_(P.oZL, e), v - lo, dv);
                 if (isfinite(hi)) slot(W_(P.oSU, e), W_(P.oZU, e), hi - v, -dv);
+                const int k = e / ns, c = e - k * ns;
+                if (k < N) {
+                    if (c < 3) dphi += 2 * P.q[c] * (v - (c == 0 ? xs0 : (c == 1 ? xs1 : xs2))) * dv;
+                    else if (P.lw != 0.0) dphi += -2.0 * P.lw / (v * v * v) * dv;
+                }
             }
-            for (int o = 0; o < 2 * Nc; o++) {
+            for (int o = lane; o < 2 * Nc; o += 64) {
                 const double u = W_(oU, o), du = W_(P.odU, o);
                 slot(W_(P.oSLu, o), W_(P.oZLu, o), u - lbu[o], du);
                 slot(W_(P.oSUu, o), W_(P.oZUu, o), ubu[o] - u, -du);
+                const int j = o >> 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
+                dphi += cnt * 2 * P.r[o & 1] * u * du;
             }
-            for (int k = 1; k < N; k++) {
-                dphi += 2 * P.q[0] * (W_(oV, k * ns) - xs0) * W_(P.odV, k * ns); dphi += 2 * P.q[1] * (W_(oV, k * ns + 1) - xs1) * W_(P.odV, k * ns + 1);
-                dphi += 2 * P.q[2] * (W_(oV, k * ns + 2) - xs2) * W_(P.odV, k * ns + 2);
-                if (P.lw != 0.0)
-                    for (int m = 0; m < R; m++) { const double d = W_(oV, k * ns + 3 + m); dphi += -2.0 * P.lw / (d * d * d) * W_(P.odV, k * ns + 3 + m); }
-            }
-            for (int o = 0; o < 2 * Nc; o++) { const int j = o >> 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1; dphi += cnt * 2 * P.r[o & 1] * W_(oU, o) * W_(P.odU, o); }
+            a_p = wmin_(a_p); a_d = wmin_(a_d); dphi = wsum_(dphi); lgs = wsum_(lgs); thh = wsum_(thh);
             // ---- E. l1 merit backtracking (non-monotone reference: max of the last merit values of this barrier problem)
             const double theta0 = th0 + thh, phi0 = f - mu * lgs;
             if (theta0 > 0.0) {
@@ -429,23 +461,29 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             if (mcount > 2) mref = fmax(mref, mh2);
             mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
             for (int ls = 0; ls < 30; ls++) {
-                for (int e = 0; e < (N + 1) * ns; e++) W_(oVt, e) = W_(oV, e) + alpha * W_(P.odV, e);
-                for (int e = 0; e < 2 * Nc; e++) W_(oUt, e) = W_(oU, e) + alpha * W_(P.odU, e);
-                ft = eval_point(oVt, oUt, false, tht, ect);
                 double lgt = 0.0, tb = 0.0;
                 auto trial = [&](double s_, double h0_, double jd_, double ht_) { const double st_ = s_ + alpha * (jd_ + (h0_ - s_)); lgt += log(st_); tb += fabs(ht_ - st_); };
-                for (int e = ns; e < (N + 1) * ns; e++) {
-                    const double v = W_(oV, e), dv = W_(P.odV, e), vt = W_(oVt, e), lo = lbv[e], hi = ubv[e];
-                    if (isfinite(lo)) trial(W_(P.oSL, e), v - lo, dv, vt - lo);
-                    if (isfinite(hi)) trial(W_(P.oSU, e), hi - v, -dv, hi - vt);
+                for (int e = lane; e < nV; e += 64) {
+                    const double v = W_(oV, e), dv = W_(P.odV, e), vt = v + alpha * dv;
+                    W_(oVt, e) = vt;
+                    if (e >= ns) {
+                        const double lo = lbv[e], hi = ubv[e];
+                        if (isfinite(lo)) trial(W_(P.oSL, e), v - lo, dv, vt - lo);
+                        if (isfinite(hi)) trial(W_(P.oSU, e), hi - v, -dv, hi - vt);
+                    }
                 }
-                for (int o = 0; o < 2 * Nc; o++) {
-                    const double u = W_(oU, o), du = W_(P.odU, o), ut = W_(oUt, o);
+                for (int o = lane; o < 2 * Nc; o += 64) {
+                    const double u = W_(oU, o), du = W_(P.odU, o), ut = u + alpha * du;
+                    W_(oUt, o) = ut;
                     trial(W_(P.oSLu, o), u - lbu[o], du, ut - lbu[o]);
                     trial(W_(P.oSUu, o), ubu[o] - u, -du, ubu[o] - ut);
                 }
+                __syncthreads();
+                ft = eval_point(oVt, oUt, false, tht, ect);
+                lgt = wsum_(lgt); tb = wsum_(tb);
                 if ((ft - mu * lgt) + nu_pen * (tht + tb) <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
                 if (ls < 29) alpha *= 0.5;
+                __syncthreads();
             }
             a_d = fmin(a_d, alpha);
             n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
@@ -456,20 +494,24 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 const double sn_ = s_ + alpha * ds_, zn_ = z_ + a_d * dz_;
                 W_(oS, e) = sn_; W_(oZ, e) = fmin(fmax(zn_, mu / (1e10 * sn_)), 1e10 * mu / sn_);
             };
-            for (int e = ns; e < (N + 1) * ns; e++) {
+            for (int e = ns + lane; e < nV; e += 64) {
                 const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
                 if (isfinite(lo)) upd(P.oSL, P.oZL, e, v - lo, dv);
                 if (isfinite(hi)) upd(P.oSU, P.oZU, e, hi - v, -dv);
             }
-            for (int o = 0; o < 2 * Nc; o++) {
+            for (int o = lane; o < 2 * Nc; o += 64) {
                 const double u = W_(oU, o), du = W_(P.odU, o);
                 upd(P.oSLu, P.oZLu, o, u - lbu[o], du);
                 upd(P.oSUu, P.oZUu, o, ubu[o] - u, -du);
             }
-            { int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_; }
-            for (int e = 3; e < (N + 1) * 3; e++) W_(P.olam, e) += alpha * (W_(P.olamn, e) - W_(P.olam, e));
-            for (int e = R; e < (N + 1) * R; e++) W_(P.oeta, e) += alpha * (W_(P.oetan, e) - W_(P.oeta, e));
+            if (alpha != 1.0 || true) {      // the trial point of the accepted step length is in (oVt, oUt)
+                int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_;
+            }
+            for (int e = 3 + lane; e < (N + 1) * 3; e += 64) W_(P.olam, e) += alpha * (W_(P.olamn, e) - W_(P.olam, e));
+            for (int e = R + lane; e < (N + 1) * R; e += 64) W_(P.oeta, e) += alpha * (W_(P.oetan, e) - W_(P.oeta, e));
+            __syncthreads();
             f = eval_point(oV, oU, true, th0, e_c);
+            __syncthreads();
             it++;
             if (n_tiny >= 5) {
                 if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
@@ -479,12 +521,15 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
         }
         if (!restarting) break;
     }
-    for (int e = 0; e < (N + 1) * ns; e++) wo[e] = W_(oV, e);
-    for (int e = 0; e < 2 * Nc; e++) wo[(size_t)(N + 1) * ns + e] = W_(oU, e);
-    if (obj_out) obj_out[b] = f;
-    if (status_out) status_out[b] = status;
-    if (iters_out) iters_out[b] = it;
-    if (kkt_out) kkt_out[b] = kkt;
+    __syncthreads();
+    for (int e = lane; e < nV; e += 64) wo[e] = W_(oV, e);
+    for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)nV + e] = W_(oU, e);
+    if (lane == 0) {
+        if (obj_out) obj_out[b] = f;
+        if (status_out) status_out[b] = status;
+        if (iters_out) iters_out[b] = it;
+        if (kkt_out) kkt_out[b] = kkt;
+    }
 }
 
 // f (V4:135-136) and g = [gx; gd] (V4:151): one thread per (instance, stage); stage N handles the initial rows
@@ -577,7 +622,8 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     P.oVt = take(nV); P.oUt = take(nU); P.osn = take(N); P.ocs = take(N); P.oHxx = take(4 * (int64_t)(N + 1)); P.ogx = take(nL); P.oWd = take(nE); P.ogdv = take(nE);
     P.ohuu = take(nU); P.ogu = take(nU); P.ohvt = take(N); P.oKg = take(6 * (int64_t)Nc); P.okff = take(nU); P.opo = take(2 * R);
     P.total = o;
-    P.S = ((int64_t)max_batch + 63) / 64 * 64;
+    P.total = (P.total + 15) / 16 * 16;      // every instance starts on a 128-byte boundary
+    P.S = max_batch;
     h->ws_bytes = (int64_t)sizeof(double) * P.total * P.S;
     if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
     if (hipMalloc((void **)&h->lb, sizeof(double) * nv) != hipSuccess || hipMalloc((void **)&h->ub, sizeof(double) * nv) != hipSuccess) {
@@ -619,14 +665,7 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    // Instances per wavefront.  Every lane runs a serial solve whose inner loops wait on HBM (the iterate does not fit on chip:
-    // ~100 KB per instance), so the kernel is bound by memory LATENCY times the length of one solve, and what hides latency is the
-    // number of wavefronts in flight, not the lanes per wavefront: the batch is spread over ~4 wavefronts per SIMD (4096 on the
-    // chip) before lanes are filled up.  NMPC_LIDAR_LANES overrides (development).
-    int lanes = (B + 4095) / 4096;
-    if (const char *e = getenv("NMPC_LIDAR_LANES")) lanes = atoi(e);
-    lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
-    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)((B + lanes - 1) / lanes)), dim3(lanes), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
+    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

@@ -1,4 +1,4 @@
-"""Development aid (GPU box): LIDAR kernel throughput against the instances-per-wavefront setting."""
+"""Development aid (GPU box): LIDAR kernel throughput (one wavefront per instance)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,9 +17,8 @@ for _ in range(B):
 Pl = torch.as_tensor(np.stack(Pl), device="cuda"); Wl = torch.as_tensor(np.stack(Wl), device="cuda")
 lbx, ubx, _, _ = LR.bounds(lc)
 s = nmpc_amd.LidarSolver(nmpc_amd.lidar_v4(), lbx=lbx, ubx=ubx, max_batch=B)
-for lanes in [int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else "64,16,4,1".split(","))]:
-    os.environ["NMPC_LIDAR_LANES"] = str(lanes)
+for lanes in [64]:
     r = s.solve_batch(Pl, Wl); torch.cuda.synchronize()
     t = time.perf_counter(); r = s.solve_batch(Pl, Wl); torch.cuda.synchronize(); dt = time.perf_counter() - t
     it = r["iters"].cpu().numpy()
-    print(f"B={B} lanes/wave {lanes:2d}: {dt*1e3:8.1f} ms  {B/dt:9.0f} solves/s  mean iters {it.mean():.1f} max {it.max()} converged {(r['status'].cpu().numpy()==0).mean():.3f}", flush=True)
+    print(f"B={B}: {dt*1e3:8.1f} ms  {B/dt:9.0f} solves/s  mean iters {it.mean():.1f} max {it.max()} converged {(r['status'].cpu().numpy()==0).mean():.3f}", flush=True)
