@@ -160,10 +160,12 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     P.order_bad = h->ord_chk + B;
     if (order && nmpc::launch_order_check(B, order, h->ord_chk, h->ord_chk + B, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
     // Launch shape.  The column-per-lane kernel (one wave per instance, two instances per SIMD up to six robots) is the
-    // throughput path.  Batches that leave most of the chip idle are latency problems instead: there the element-per-lane kernel
-    // spreads one instance over 2-4 waves (five / six robots: B <= 512; eight / ten robots: B <= 512), measured faster per solve.
+    // throughput path.  A batch that cannot fill those slots is a latency problem instead (the launch lasts as long as its longest
+    // solve): there the element-per-lane kernel, one instance per SIMD and, for still smaller batches, 2-4 waves per instance, is
+    // faster.  Measured on the six-robot workload (solves/s, column | element): B=2048 75 k | 87 k, 4096 117 k | 104 k,
+    // 8192 148 k | 129 k, 16384 176 k | 143 k; ten robots N=30 B=512 4.1 k | 4.6 k, N=20 B=4096 40 k | 27 k.
     int kern = h->kernel;
-    if (kern == 3 && h->lat_ok && B <= 512 && h->cfg.m >= 5) kern = 2;
+    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 1024) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 2048))) kern = 2;
     hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                    : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)
                                  : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);

@@ -90,3 +90,13 @@ def test_oracle_matches_slsqp_small():
         assert r["status"][0] == 0
         assert abs(r["f"][0] - res.fun) <= 1e-6 * max(1.0, abs(res.fun)), (r["f"][0], res.fun)
         assert np.abs(r["x"][0] - res.x).max() < 2e-4
+
+
+def test_oracles_are_clean_under_asan_and_ubsan():
+    """VERDICT r1 / SURVEY 5: `-fsanitize=address,undefined` on the CPU restatement (GPU sanitizers are not available on this
+    pool): both oracles solve fixed problems under ASan + UBSan + leak check (oracle/asan_driver.c, `make -C oracle asan_check`)."""
+    import os, subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", here, "-B", "asan_check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
