@@ -133,7 +133,9 @@ def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version):
     fl_iter = algorithmic_flops_per_iter(ocfg)
     flops_launch = float(sum_iters) * fl_iter
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
-    rl = {"bound": "fp64-valu", "kernel": "nmpc::solve_lds_kernel<%d,...>" % ocfg.m, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+    # the kernel nmpc_solve_batch picks for this team size and batch (nmpc_api.cpp): column-per-lane for throughput batches
+    col = ocfg.m <= 4 or (ocfg.m <= 6 and B > 2048) or (ocfg.m >= 8 and B > 1024)
+    rl = {"bound": "fp64-valu", "kernel": "nmpc::solve_%s_kernel<%d,...>" % ("col" if col else "lds", ocfg.m), "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
           "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
           "hbm_frac_of_algorithmic_bytes": algorithmic_bytes_per_solve(ocfg) * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 5 --warmup 1 --cpu-sample 0 --closed-loop 0"
+ARGS="$ROOT/bench.py --steps 5 --warmup 1 --cpu-sample 0 --closed-loop 0 --sweep 0"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o run -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o run -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/write.err
