@@ -5,6 +5,14 @@
 
 #include "../../include/nmpc.h"
 
+// inertia correction: factor between consecutive trial shifts of one iteration once a previous iteration needed a shift (IPOPT's
+// kappa_w^+ = 8).  Measured this round with 4: on the cold six-robot bench batch the literal antipodal swap drops from 113
+// to 67 iterations and the 99th percentile from 70 to 63 at the same total number of sweeps (120.7 k vs 117.9 k solves/s), but the warm
+// closed loop falls from 148.8 k to 110.8 k solves/s and the composite from 17.1 k to 12.0 k: kept at 8.  Shared by all kernels.
+#ifndef NMPC_SHIFT_ESCALATION
+#define NMPC_SHIFT_ESCALATION 8.0
+#endif
+
 namespace nmpc {
 
 // Passed by value to every kernel (lands in SGPRs / the kernarg segment).

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             __syncthreads();
             ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-            else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+            else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
         }
         if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
