@@ -602,7 +602,9 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                         else {
                             // multipliers M[j][a], a > j: rows a < RL_SPLIT through v_readlane (2 VALU instructions each, the SIMD's own
                             // pipe), rows a >= RL_SPLIT through one LDS broadcast of the pivot row (uniform-address ds_read_b128, two rows
-                            // each, the pipe the four SIMDs of a CU share): the split balances the two pipes at full occupancy
+                            // each, the pipe the four SIMDs of a CU share).  Measured (A/B in one session): all-readlane wins at
+                            // every team size (six robots 117 k vs 101 k solves/s, ten robots 39.4 k vs 34.4 k); a ds_bpermute with a uniform
+                            // source lane (no LDS write, no wait) is slower still (ten robots 23 k)
                             constexpr int RL_SPLIT = NMPC_RL_SPLIT(NU, NZ);
                             double *br = BR + (j & 1) * 64;
                             if constexpr (RL_SPLIT < NZ) br[tid] = m[j];
@@ -613,7 +615,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                             if constexpr (RL_SPLIT < NZ) lds_sync<TPB>();
                             auto mult = [&](auto ac) {
                                 constexpr int a = decltype(ac)::value;
-                                if constexpr (a < RL_SPLIT) return lane_read(m[j], LC(a)); else return br[LC(a)];
+                                if constexpr (a < RL_SPLIT) return lane_read(m[j], LC(a));
+                                else return br[LC(a)];
                             };
                             if constexpr (j + 1 < NU) {       // the next pivot row first: its reciprocal overlaps the other rows
                                 m[j + 1] = fma(-mult(std::integral_constant<int, j + 1>{}), rjv, m[j + 1]);

@@ -20,7 +20,7 @@ importlib.import_module("nmpc_amd.build").build(force=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 REPS = int(os.environ.get("PHASE_REPS", "1"))
 name = sys.argv[2] if len(sys.argv) > 2 else "six"
-ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(30)}[name]
+ocfg = {"six": R.cfg_six(20), "two": R.cfg_two(20), "ten": R.cfg_ten(30), "ten20": R.cfg_ten(20)}[name]
 cfg = Hh.to_product_cfg(ocfg, max_iter=2000)
 P, W0 = Hh.batch(ocfg, B, 2)
 s = nmpc_amd.NmpcSolver(cfg, max_batch=B)
