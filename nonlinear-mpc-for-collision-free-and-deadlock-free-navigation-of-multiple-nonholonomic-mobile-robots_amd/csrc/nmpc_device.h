@@ -13,6 +13,15 @@
 #define NMPC_SHIFT_ESCALATION 8.0
 #endif
 
+// Cold-start retry (restoration of last resort): a solve that stalls after its barrier restarts, fails numerically or is still
+// iterating NMPC_COLD_RETRY_ITERS iterations into an attempt is restarted from the reference's cold start X_k = x0, U = 0 (C6:398-400), at most
+// NMPC_COLD_RETRIES times, the second time with a ten times larger initial barrier parameter.  Mirrored in oracle/nmpc_oracle.c.
+#define NMPC_COLD_RETRY_ITERS 500
+#define NMPC_COLD_RETRIES 2
+// slack of the stage-0 feasibility pre-check (status 3): a measured x0 that violates a pair / obstacle row by less than this — the
+// previous period's plan holds its rows to the solve tolerance only — is not reported as infeasible
+#define NMPC_X0_TOL 1e-6
+
 namespace nmpc {
 
 // Passed by value to every kernel (lands in SGPRs / the kernarg segment).

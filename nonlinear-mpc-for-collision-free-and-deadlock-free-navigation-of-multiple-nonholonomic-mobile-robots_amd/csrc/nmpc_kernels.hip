@@ -228,12 +228,12 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         for (int q = tid; q < NPA; q += TPB) {
             int i = sPi[q], j = sPj[q];
             double dx = pp[3 * i] - pp[3 * j], dy = pp[3 * i + 1] - pp[3 * j + 1];
-            if (dx * dx + dy * dy < P.dmin2) bad = 1.0;
+            if (dx * dx + dy * dy < P.dmin2 - NMPC_X0_TOL) bad = 1.0;
         }
         for (int e = tid; e < M_ * P.K; e += TPB) {
             int i = e / P.K, o = e - i * P.K;
             double dx = pp[3 * i] - P.obs[3 * o], dy = pp[3 * i + 1] - P.obs[3 * o + 1];
-            if (sqrt(dx * dx + dy * dy) - P.robdim - P.obs[3 * o + 2] < P.margin) bad = 1.0;
+            if (sqrt(dx * dx + dy * dy) - P.robdim - P.obs[3 * o + 2] < P.margin - NMPC_X0_TOL) bad = 1.0;
         }
         bad = blk_max<TPB>(bad, sRed);
         if (bad > 0.0) {
@@ -326,6 +326,30 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     int mcount = 0;
     int iter = 0, status = NMPC_STATUS_MAX_ITER;
     const double n_ineq = (double)P.n_ineq;
+    // (Re)start of the barrier iteration from the current primal point, or — cold — from the reference's cold start X_k = x0, U = 0
+    // (C6:398-400; the cold-start retry of NMPC_COLD_RETRY_ITERS): interior push, slacks onto the constraint values, duals mu/s, multipliers 0
+    int n_cold = 0, it_base = 0;
+    auto do_restart = [&](bool cold) {
+        if (cold) { n_cold++; it_base = iter; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; }
+        for (int e = tid + NX; e < (N + 1) * NX; e += TPB) {
+            if (cold) X[e] = X[e % NX];
+            const int d = (e % NX) % 3;
+            if (d < 2 || P.thb) {
+                double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
+                X[e] = fmin(fmax(X[e], -b + px), b - px);
+            }
+            LAM[e] = 0.0;
+        }
+        for (int e = tid; e < N * NU; e += TPB) {
+            double lo = lbu(P, e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
+            U[e] = fmin(fmax(cold ? 0.0 : U[e], lo + pu), hi - pu);
+        }
+        __syncthreads();
+        f = eval_point();
+        __syncthreads();
+        init_barrier();
+        delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0;
+    };
 
     for (;;) {
         // ================= optimality error (IPOPT eq. 5), residuals per (stage, robot)
@@ -373,9 +397,10 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         double s_c = fmax(smax, zsum / fmax(n_ineq, 1.0)) / smax;
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
         kkt = E0;
-        if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+        if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && iter < P.max_iter) { do_restart(true); continue; } status = NMPC_STATUS_NUMERIC; break; }
         if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
         if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+        if (n_cold < NMPC_COLD_RETRIES && iter - it_base >= NMPC_COLD_RETRY_ITERS) { do_restart(true); continue; }
         // ================= monotone barrier update (IPOPT eq. 7)
         const double mu_min = P.tol / 10.0;
         for (;;) {
@@ -620,7 +645,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
         }
-        if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+        if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { do_restart(true); iter++; continue; } status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;
         need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
 
@@ -778,27 +803,11 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         __syncthreads();
         iter++;
         if (n_tiny >= 5) {
-            if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+            if (n_restart >= 3) { if (n_cold < NMPC_COLD_RETRIES) { do_restart(true); continue; } status = NMPC_STATUS_STALLED; break; }
             // barrier restart from the current primal point (restoration in miniature, see the oracle)
             n_restart++; n_tiny = 0;
             mu = fmax(mu, P.mu_init);
-            for (int e = tid + NX; e < (N + 1) * NX; e += TPB) {
-                const int d = (e % NX) % 3;
-                if (d < 2 || P.thb) {
-                    double b = (d == 2) ? P.thmax : P.xymax, px = fmin(bp * fmax(1.0, b), bp * 2.0 * b);
-                    X[e] = fmin(fmax(X[e], -b + px), b - px);
-                }
-                LAM[e] = 0.0;
-            }
-            for (int e = tid; e < N * NU; e += TPB) {
-                double lo = lbu(P, e % NU), hi = -lo, pu = fmin(bp * fmax(1.0, fabs(lo)), bp * (hi - lo));
-                U[e] = fmin(fmax(U[e], lo + pu), hi - pu);
-            }
-            __syncthreads();
-            f = eval_point();
-            __syncthreads();
-            init_barrier();
-            delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0;
+            do_restart(false);
         }
     }
 

@@ -504,9 +504,7 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 upd(P.oSLu, P.oZLu, o, u - lbu[o], du);
                 upd(P.oSUu, P.oZUu, o, ubu[o] - u, -du);
             }
-            if (alpha != 1.0 || true) {      // the trial point of the accepted step length is in (oVt, oUt)
-                int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_;
-            }
+            { int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_; }      // the trial point of the accepted step length is in (oVt, oUt)
             for (int e = 3 + lane; e < (N + 1) * 3; e += 64) W_(P.olam, e) += alpha * (W_(P.olamn, e) - W_(P.olam, e));
             for (int e = R + lane; e < (N + 1) * R; e += 64) W_(P.oeta, e) += alpha * (W_(P.oetan, e) - W_(P.oeta, e));
             __syncthreads();

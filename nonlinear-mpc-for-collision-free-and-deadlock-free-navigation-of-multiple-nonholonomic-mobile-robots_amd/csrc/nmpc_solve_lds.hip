@@ -172,12 +172,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             while (r >= M_ - 1 - i) { r -= M_ - 1 - i; i++; }
             int j = i + 1 + r;
             double dx = X[3 * i] - X[3 * j], dy = X[3 * i + 1] - X[3 * j + 1];
-            if (h_pair(dx, dy, P.dmin2) < 0.0) bad = 1.0;
+            if (h_pair(dx, dy, P.dmin2) < -NMPC_X0_TOL) bad = 1.0;
         }
         for (int e = tid; e < MK; e += TPB) {
             int i = e / K, o = e - i * K;
             double dx = X[3 * i] - P.obs[3 * o], dy = X[3 * i + 1] - P.obs[3 * o + 1];
-            if (h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin) < 0.0) bad = 1.0;
+            if (h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin) < -NMPC_X0_TOL) bad = 1.0;
         }
         bad = wmax<TPB>(bad, RED);
         if (bad > 0.0) {
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     };
     double f, lgs, th0, e_c, e_h;
     double delta_last, nu_pen, kkt = INFINITY;
-    bool need_shift, restarting = false;
+    bool need_shift, restarting = false, cold = false;
+    int n_cold = 0, it_base = 0;      // cold-start retries done / iteration at which the current attempt started (NMPC_COLD_RETRY_ITERS)
     int n_tiny = 0, n_restart = 0;      // consecutive iterations with a step length below 1e-10 (stall -> restart, then NMPC_STATUS_STALLED)
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   // merit values of the last three iterates (same mu, nu)
     int mcount;
@@ -320,6 +321,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     // values, duals = mu / s, multipliers = 0.  One call site for the initialisation keeps the register budget of the main loop.
     for (;;) {
     if (restarting) {
+        if (cold) {       // the reference's cold start (C6:398-400): X_k = x0, U = 0
+            for (int e = tid + NX; e < N1 * NX; e += TPB) X[e] = X[e % NX];
+            for (int e = tid; e < N * NU; e += TPB) U[e] = 0.0;
+            cold = false;
+            __syncthreads();
+        }
         for (int e = tid + NX; e < N1 * NX; e += TPB) {
             const int d = (e % NX) % 3;
             if (d < 2 || THB) {
@@ -430,9 +437,11 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         double s_c = fmax(smax, zsum / fmax(n_ineq, 1.0)) / smax;
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
         kkt = E0;
-        if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+        auto cold_retry = [&]() { cold = true; n_cold++; it_base = iter; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
+        if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && iter < P.max_iter) cold_retry(); else status = NMPC_STATUS_NUMERIC; break; }
         if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
         if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+        if (n_cold < NMPC_COLD_RETRIES && iter - it_base >= NMPC_COLD_RETRY_ITERS) { cold_retry(); break; }
         const double mu_min = P.tol / 10.0;
         for (;;) {
             double cm = fmax(fabs(szmax - mu), fabs(szmin - mu));
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
         }
-        if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+        if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); iter++; } else status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;
         need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
         __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
@@ -1021,7 +1030,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         iter++;
         PROF_T(8);
         if (n_tiny >= 5) {
-            if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+            if (n_restart >= 3) { if (n_cold < NMPC_COLD_RETRIES) cold_retry(); else status = NMPC_STATUS_STALLED; break; }
             n_restart++; n_tiny = 0;
             mu = fmax(mu, P.mu_init);
             restarting = true;

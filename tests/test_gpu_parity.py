@@ -330,20 +330,41 @@ def test_odometry_front_end(built):
     assert np.allclose(pose, [R.C2_START[0] + 0.1 * np.cos(0.785), R.C2_START[1] + 0.1 * np.sin(0.785), 0.985], atol=1e-15)
 
 
-def test_stalled_solve_reports_status_4(built):
-    """tests/golden/stall_case.npz: a warm-started six-robot solve captured from a closed-loop soak (step 67 of swarm 260,
-    tools/soak_failures.py) that converges to an infeasible stationary point (theta stuck at 1.07, slacks pinned at zero).
-    IPOPT would switch to restoration; both implementations stop after 5 consecutive steps below 1e-10 with
-    NMPC_STATUS_STALLED instead of burning max_iter iterations (one such instance used to hold a 4096-batch for 0.4 s)."""
+def test_cold_start_retry_rescues_stalls_and_cyclers(built):
+    """tests/golden/stall_case.npz (a warm-started six-robot solve that converges to an infeasible stationary point; IPOPT would
+    switch to restoration) and tests/golden/cold_retry_cases.npz (the 11 of 10,240 composite closed-loop solves that stall or cycle
+    until max_iter without it; cold_retry_cases2.npz: 5 more that need the second retry): after three barrier restarts — or 500 iterations
+    of an attempt without convergence — the solve restarts from the reference's own cold start X_k = x0, U = 0 (C6:398-400), at most twice (the
+    second time with mu = 10 mu_init), and converges, on every kernel, like the oracle."""
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
     ocfg = R.cfg_six(20)
     ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"][None], d["w"][None])
-    r = _np(_solver(ocfg, 1, max_iter=2000).solve_batch(d["p"][None], d["w"][None]))
-    assert ref["status"][0] == 4 and r["status"][0] == 4, (ref["status"], r["status"])
-    # three barrier restarts (slacks / duals re-initialised from the interior-pushed current point) are tried before giving up
-    assert ref["iters"][0] < 1000 and abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 10
-    assert abs(r["kkt"][0] - ref["kkt"][0]) <= 1e-2 * ref["kkt"][0]
+    assert ref["status"][0] == 0 and ref["iters"][0] > 300
+    for kernel in (None, "3", "2", "1"):
+        r = _np(_solver(ocfg, 1, max_iter=2000, kernel=kernel).solve_batch(d["p"][None], d["w"][None]))
+        assert r["status"][0] == 0 and r["kkt"][0] <= 1e-8, (kernel, r["status"], r["iters"], r["kkt"])
+        assert abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 25, (kernel, r["iters"], ref["iters"])
+        assert abs(r["f"][0] - ref["f"][0]) <= 1e-6 * max(1.0, abs(ref["f"][0]))
+    z1 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cold_retry_cases.npz"))
+    z2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cold_retry_cases2.npz"))      # need the second retry (mu = 10 mu_init)
+    z = {"p": np.concatenate([z1["p"], z2["p"]]), "w": np.concatenate([z1["w"], z2["w"]])}
+    ccfg = _composite_cfg()
+    refc = O.solve_batch(O.make_config(ccfg, max_iter=2000), z["p"], z["w"])
+    assert (refc["status"] == 0).all()
+    for kernel in ("3", "2"):
+        rc = _np(_solver(ccfg, len(z["p"]), max_iter=2000, kernel=kernel).solve_batch(z["p"], z["w"]))
+        assert (rc["status"] == 0).all() and (rc["kkt"] <= 1e-8).all(), (kernel, rc["status"], rc["iters"])
+        # long, chaotic solves (300-700 iterations): the KKT point is what is compared, where the basin is the same
+        same = np.max(np.abs(rc["x"] - refc["x"]), axis=1) <= W_TOL
+        assert same.mean() >= 0.4, (kernel, same)
+        for b in np.where(~same)[0][:3]:
+            k = R.kkt_report(ccfg, rc["x"][b], z["p"][b], tol_active=1e-3)
+            # feasibility is checked independently; stationarity is NOT asserted through the least-squares report here: these are the
+            # degenerate points of the batch (robots wedged between obstacles, dependent active rows, multipliers of 1e4 and beyond), where
+            # the solver's criterion — IPOPT's error SCALED by the multiplier norm — is met (kkt <= 1e-8 above) while a least-squares
+            # multiplier fit with bounded iterations is not meaningful
+            assert k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
 
 
 def test_barrier_restart_rescues_composite_stalls(built):
@@ -409,3 +430,18 @@ def test_dispatch_order_hint_does_not_change_results(built):
             assert np.array_equal(r0[k], r1[k]), k
     with pytest.raises(ValueError):
         s.solve_batch(P, W0, order=np.arange(B - 1))
+
+
+def test_composite_closed_loop_soak_has_no_failed_solve(built):
+    """VERDICT r1 item 9, reduced size: 192 swarms x 40 control periods of the six-robot + eight-obstacle composite (BASELINE config 5)
+    on the HIP path — every one of the 7,680 warm-started solves converges (the full 512 x 60 soak of tools/soak_composite.py:
+    30,720 solves, 0 failed; before the cold-start retry 0.23 % failed), no swarm ever violates a pair distance or an obstacle margin."""
+    import nmpc_amd
+    ocfg = _composite_cfg()
+    B = 192
+    P, _ = Hh.batch(ocfg, B, 4)
+    s = _solver(ocfg, B, max_iter=2000)
+    ep = nmpc_amd.simulate_closed_loop(s, P[:, : ocfg.nx], P[:, ocfg.nx:], max_steps=40, stop_tol=1e-3)
+    print(f"composite soak: {ep.total_solves} solves, failed {ep.failed_solves}, collision-free {ep.collision_free.mean():.3f}, mean iterations {ep.mean_iters_by_step.mean():.1f}")
+    assert ep.total_solves == B * 40 and ep.failed_solves == 0
+    assert ep.collision_free.all()

@@ -122,33 +122,33 @@ def test_closed_loop_episode_stays_collision_free_and_converged():
     assert (d1 < d0).all()
 
 
-def test_stall_case_is_reported_not_iterated_to_the_limit():
-    """the captured infeasible-stationary-point case (see tests/test_gpu_parity.py::test_stalled_solve_reports_status_4)."""
+def test_stall_case_and_composite_failures_are_rescued_by_the_cold_start_retry():
+    """tests/golden/stall_case.npz: a warm-started six-robot solve that converges to an infeasible stationary point (IPOPT would
+    enter restoration): three barrier restarts do not help; the restoration of last resort — a restart from the reference's own
+    cold start X_k = x0, U = 0 (C6:398-400), at most twice, the second time with mu = 10 mu_init — converges.  tests/golden/cold_retry_cases.npz: the 11 of 10,240 closed-loop solves
+    of the six-robot + eight-obstacle composite that fail without the retry (stall, or cycling until max_iter; generator
+    gen_cold_retry_cases.py runs the oracle with NMPC_ORACLE_NO_COLD_RETRY=1): all converge, the cyclers through the
+    iteration watchdog (500)."""
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
     r = O.solve_batch(O.make_config(R.cfg_six(20), max_iter=2000), d["p"][None], d["w"][None])
-    assert r["status"][0] == 4 and r["iters"][0] < 1000 and r["kkt"][0] > 1e-3      # three barrier restarts are tried first
-
-
-def test_no_pair_rows_nlp_is_separable():
-    """AS/mpc_online_casadi_tb3_multi_centralized.py:115-148: two robots, g = 6(N+1) rows (no pair rows, no padding rows).
-    Layout, and the solve against the two single-robot solves it decomposes into."""
-    cfg = R.cfg_two_nopairs(50)
-    assert cfg.n_g == 6 * 51 and cfg.M == 0 and cfg.rows0 == 6 and cfg.rows_k == 6
-    lbx, ubx, lbg, ubg = R.bounds(cfg)
-    assert lbg.shape == (6 * 51,) and not lbg.any() and not ubg.any()
-    rng = np.random.Generator(np.random.PCG64(Hh.SEED0 + 91))
-    P = np.stack([Hh.instance(rng, cfg) for _ in range(4)])
-    P[:, 6:] = P[:, :6] + rng.uniform(-0.15, 0.15, (4, 6))
-    W0 = np.stack([R.cold_start(cfg, q[:6]) for q in P])
-    r = O.solve_batch(O.make_config(cfg, max_iter=1000), P, W0)
-    assert (r["status"] == 0).all()
-    c1 = R.cfg_one(50); c1.T = cfg.T
-    p1 = np.concatenate([P[:, :6].reshape(4, 2, 3), P[:, 6:].reshape(4, 2, 3)], axis=2).reshape(8, 6)
-    r1 = O.solve_batch(O.make_config(c1, max_iter=1000), p1, np.stack([R.cold_start(c1, q[:3]) for q in p1]))
-    assert (r1["status"] == 0).all()
-    X = r1["x"][:, : 3 * 51].reshape(4, 2, 51, 3).transpose(0, 2, 1, 3).reshape(4, -1)
-    U = r1["x"][:, 3 * 51:].reshape(4, 2, 50, 2).transpose(0, 2, 1, 3).reshape(4, -1)
-    assert np.abs(np.concatenate([X, U], axis=1) - r["x"]).max() < 1e-5
-    for b in range(4):
-        k = R.kkt_report(cfg, r["x"][b], P[b], tol_active=1e-3)
-        assert k["stat"] < 1e-5 and k["eq"] < 1e-8, k
+    assert r["status"][0] == 0 and 300 < r["iters"][0] < 1000 and r["kkt"][0] <= 1e-8
+    k = R.kkt_report(R.cfg_six(20), r["x"][0], d["p"], tol_active=1e-3)
+    assert k["stat"] < 1e-5 and k["eq"] < 1e-8 and k["ineq"] < 1e-8, k
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cold_retry_cases.npz"))
+    rng = np.random.default_rng(7)
+    c = R.cfg_six(25); c.rob_dim = 0.2; c.margin = 0.1
+    c.obstacles = [(float(x), float(y), float(r_)) for x, y, r_ in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
+    rr = O.solve_batch(O.make_config(c, max_iter=2000), z["p"], z["w"])
+    assert len(z["p"]) == 11 and (rr["status"] == 0).all() and (rr["kkt"] <= 1e-8).all(), (rr["status"], rr["iters"])
+    # cold_retry_cases2.npz: the 5 root failures left in a 512 x 60 soak on the GPU with ONE retry (tools/soak_composite.py): the cold start
+    # itself fails with mu_init = 0.5 on four of them; the second retry (cold start, mu = 10 mu_init) converges on all
+    z2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cold_retry_cases2.npz"))
+    r2 = O.solve_batch(O.make_config(c, max_iter=2000), z2["p"], z2["w"])
+    assert len(z2["p"]) == 5 and (r2["status"] == 0).all() and (r2["kkt"] <= 1e-8).all(), (r2["status"], r2["iters"])
+    # without the retry the same inputs fail (what the fixture was captured for)
+    import subprocess, sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from oracle import nlp_ref as R, oracle_lib as O; "
+            "d = np.load(%r); r = O.solve_batch(O.make_config(R.cfg_six(20), max_iter=2000), d['p'][None], d['w'][None]); print('STATUS', r['status'][0])"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, NMPC_ORACLE_NO_COLD_RETRY="1"), timeout=300)
+    assert "STATUS 4" in out.stdout, (out.stdout, out.stderr[-500:])
