@@ -157,3 +157,21 @@ def test_lidar_edge_cases(built):
     c2 = _product(cfg); c2.Nc = cfg.N + 1
     assert L.nmpc_lidar_create(C.byref(c2.to_c()), lbx.ctypes.data_as(dp), ubx.ctypes.data_as(dp), 4, C.byref(h)) == -1
     assert L.nmpc_lidar_n_var(None) == -1
+
+
+def test_lidar_full_size_batch_matches_oracle(built):
+    """2048 V4 instances (N=100, Nc=50, the script's bounds as built) — the size class of the bench entry — against the oracle on every one."""
+    import torch
+    import nmpc_amd
+    cfg = LR.lidar_v4()
+    B = 2048
+    P, W0 = _batch(cfg, B, 23)
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    r = _np(nmpc_amd.LidarSolver(_product(cfg), lbx=lbx, ubx=ubx, max_batch=B).solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.lidar_solve_batch(cfg, P, W0)
+    conv = ref["status"] == 0
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    print(f"lidar V4 B={B}: status equal {(r['status'] == ref['status']).mean():.4f}, converged {conv.mean():.4f}, same point {(dw[conv] <= W_TOL).mean():.4f}, "
+          f"identical iteration counts {(r['iters'] == ref['iters']).mean():.4f}, max iterations {r['iters'].max()}")
+    assert (r["status"] == ref["status"]).mean() >= 0.999 and conv.mean() >= 0.99
+    assert (dw[conv] <= W_TOL).mean() >= 0.99 and (r["iters"] == ref["iters"])[conv].mean() >= 0.97

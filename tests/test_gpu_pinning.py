@@ -217,3 +217,27 @@ def test_longest_lds_horizon_in_every_launch_shape(built):
         outs.append(r["x"][:2])
     for o in outs:
         assert np.abs(o - ref["x"]).max() <= 1e-6 or (ref["status"] != 0).any()
+
+
+@pytest.mark.parametrize("name,B", [("two", 4096), ("six", 4096), ("ten20", 512)])
+def test_full_size_bench_batches_match_oracle(built, name, B):
+    """the parity tests ran batches of 8-128; this one runs the bench batches themselves (bench.make_batch: the north-star
+    shapes N_robots in {2, 6, 10}, N=20, incl. the literal start/goal sets as instance 0) — 4096 instances for two and six robots, the
+    first 512 of the ten-robot batch (the CPU oracle needs ~0.1 s per ten-robot solve) — through the kernel nmpc_solve_batch picks at
+    that size, against the oracle on every instance: status, iteration count, iterate (1e-6), objective."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ocfg, _, P, W0 = bench.make_batch(name, 0, B)
+    r = _np(_solver(ocfg, B, max_iter=2000).solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), P, W0)
+    assert (r["status"] == ref["status"]).all() and (r["status"] == 0).all()
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    same = dw <= 1e-6
+    print(f"{name} B={B}: same basin {same.mean():.4f}, identical iteration counts {(r['iters'] == ref['iters']).mean():.4f}, "
+          f"mean iterations {r['iters'].mean():.2f}, max {r['iters'].max()}")
+    assert same.mean() >= 0.99 and (r["iters"] == ref["iters"]).mean() >= 0.97
+    rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
+    assert (rel[same] <= 1e-6).all() and (r["kkt"] <= 1e-8).all()
+    assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
