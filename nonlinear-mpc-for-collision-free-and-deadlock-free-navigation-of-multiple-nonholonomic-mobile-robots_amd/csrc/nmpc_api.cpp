@@ -147,6 +147,14 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
 
 int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 0; }
 
+// which solve kernel a batch of B instances runs on: 1 HBM-resident, 2 element-per-lane (latency shapes), 3 column-per-lane (throughput)
+static int kernel_for_batch(const nmpc_handle_t *h, int32_t B)
+{
+    int kern = h->kernel;
+    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 1024) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 2048))) kern = 2;
+    return kern;
+}
+
 static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                           int32_t *iters, double *kkt, const int32_t *order, void *stream)
 {
@@ -164,8 +172,7 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     // solve): there the element-per-lane kernel, one instance per SIMD and, for still smaller batches, 2-4 waves per instance, is
     // faster.  Measured on the six-robot workload (solves/s, column | element): B=2048 75 k | 87 k, 4096 117 k | 104 k,
     // 8192 148 k | 129 k, 16384 176 k | 143 k; ten robots N=30 B=512 4.1 k | 4.6 k, N=20 B=4096 40 k | 27 k.
-    int kern = h->kernel;
-    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 1024) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 2048))) kern = 2;
+    const int kern = kernel_for_batch(h, B);
     hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                    : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)
                                  : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
@@ -216,6 +223,9 @@ int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, d
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;
     return nmpc::launch_odometry((long)n, odom, init, pose, wrap_2pi != 0, (hipStream_t)stream) == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
+
+/* development aid (not part of include/nmpc.h): the kernel nmpc_solve_batch would launch for a batch of B (1 / 2 / 3, see kernel_for_batch) */
+int32_t nmpc_debug_kernel_choice(nmpc_handle_t *h, int32_t B) { return h ? kernel_for_batch(h, B) : NMPC_E_ARG; }
 
 /* development aid (not part of include/nmpc.h): per-phase cycle counters of an NMPC_PROFILE build */
 int32_t nmpc_debug_profile(nmpc_handle_t *h, int64_t *out12, int32_t reset)

@@ -241,3 +241,48 @@ def test_full_size_bench_batches_match_oracle(built, name, B):
     rel = np.abs(r["f"] - ref["f"]) / np.maximum(1.0, np.abs(ref["f"]))
     assert (rel[same] <= 1e-6).all() and (r["kkt"] <= 1e-8).all()
     assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
+
+
+def test_kernel_selection_by_team_size_and_batch(built):
+    """nmpc_solve_batch picks the column-per-lane kernel (3) for throughput batches and the multi-wave element-per-lane shapes (2) where a
+    batch cannot fill its slots (measured crossovers); NMPC_KERNEL pins one; horizons beyond the LDS fall back to 1."""
+    import nmpc_amd
+    def choice(ocfg, B, kernel=None, max_batch=8192):
+        import os
+        old = os.environ.pop("NMPC_KERNEL", None)
+        try:
+            if kernel:
+                os.environ["NMPC_KERNEL"] = kernel
+            s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg), max_batch=max_batch)
+            return [s.lib.nmpc_debug_kernel_choice(s._h, b) for b in B]
+        finally:
+            os.environ.pop("NMPC_KERNEL", None)
+            if old is not None:
+                os.environ["NMPC_KERNEL"] = old
+    assert choice(R.cfg_two(20), [1, 512, 4096]) == [3, 3, 3]
+    assert choice(R.cfg_six(20), [1, 2048, 2049, 4096]) == [2, 2, 3, 3]
+    assert choice(R.cfg_ten(20), [512, 1024, 1025, 4096]) == [2, 2, 3, 3]
+    assert choice(R.cfg_six(20), [1, 4096], kernel="3") == [3, 3] and choice(R.cfg_six(20), [1, 4096], kernel="2") == [2, 2]
+    # the column kernel keeps only what the sweeps touch in LDS: six robots fit up to ~190 stages (element-per-lane kernel: 88)
+    assert choice(R.cfg_six(120), [1, 64], max_batch=64) == [3, 3]
+    assert choice(R.cfg_six(240), [1, 64], max_batch=64) == [1, 1]          # beyond the LDS of either LDS kernel: HBM-resident fallback
+
+
+def test_long_horizon_on_the_column_kernel(built):
+    """six robots over 150 stages (117 KB of LDS per instance, above the 64 KB default: the launcher raises the kernel's dynamic LDS limit)
+    on the column-per-lane kernel against the oracle."""
+    import os
+    import torch
+    import nmpc_amd
+    ocfg = R.cfg_six(150)
+    P, W0 = Hh.batch(ocfg, 3, 2)
+    os.environ["NMPC_KERNEL"] = "3"
+    try:
+        s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=1500), max_batch=3)
+        assert s.lib.nmpc_debug_kernel_choice(s._h, 3) == 3
+    finally:
+        os.environ.pop("NMPC_KERNEL", None)
+    r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=1500), P, W0)
+    assert (r["status"] == ref["status"]).all() and (r["status"] == 0).all(), (r["status"], ref["status"], r["iters"])
+    assert np.max(np.abs(r["x"] - ref["x"]), axis=1).max() <= 1e-6 or (np.max(np.abs(r["x"] - ref["x"]), axis=1) <= 1e-6).mean() >= 0.66
