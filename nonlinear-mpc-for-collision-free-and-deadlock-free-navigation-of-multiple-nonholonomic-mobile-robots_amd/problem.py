@@ -112,3 +112,59 @@ def six_robots_eight_obstacles(N: int = 25, obstacles=None) -> ProblemConfig:
     c.obstacles = list(obstacles or [])
     c.rob_dim, c.margin = 0.2, 0.1
     return c
+
+
+# ---- every remaining script of AS/ that builds this NLP, as a parameter set ---------------------
+# (the reference copies one file per scenario; the NLP differs only in these literals.)
+# name -> (m, N, T, dmin, extra kwargs); cited lines hold T/N/m/dmin, v/omega limits and `args`.
+_PAIR = dict(v_max=0.22, w_max=2.84)
+_SOLO = dict(v_max=0.22, w_max=2.84, dmin=0.0, pad_rows=False)
+_OBS = dict(dmin=0.0, pad_rows=False, v_max=0.2, w_max=math.pi / 4, th_max=2 * math.pi, rob_dim=0.15, margin=0.05)
+_SCRIPT_TABLE = {
+    "first_scenario":                   (1, 100, 0.05, dict(_SOLO)),                  # AS/first_scenario.py:58-63,131-133
+    "second_scenario":                  (2, 50, 0.1, dict(_PAIR, dmin=0.25)),         # AS/second_scenario.py:80-88,181-183
+    "third_scenario":                   (3, 50, 0.05, dict(_PAIR, dmin=0.3)),         # AS/third_scenario.py:92-100,206-209
+    "fourth_scenario":                  (4, 50, 0.1, dict(_PAIR, dmin=0.3)),          # AS/fourth_scenario.py:104-112,229-232
+    "fifth_scenario":                   (5, 35, 0.1, dict(_PAIR, dmin=0.3)),          # AS/fifth_scenario.py:115-123,241-244
+    "sixth_scenario":                   (6, 35, 0.3, dict(_PAIR, dmin=0.3)),          # AS/sixth_scenario.py:127-135,279-282
+    "decentralized_first_scenario":     (1, 200, 0.05, dict(_SOLO, xy_max=2.0)),      # AS/decentralized_first_scenario.py:94-100,183-185
+    "decentralized_two_robots":         (2, 50, 0.1, dict(_PAIR, dmin=0.25)),         # AS/decentralized_two_robots.py:80-88,180-182
+    "centralized_three_robots":         (3, 60, 0.05, dict(_PAIR, dmin=0.15)),        # AS/centralized_three_robots_implementation.py:127-135,241-244
+    "centralized_four_robots":          (4, 45, 0.1, dict(_PAIR, dmin=0.4)),          # AS/centralized_four_robots_implementation.py:150-158,275-278
+    "centralized_five_robots":          (5, 40, 0.1, dict(_PAIR, dmin=0.4)),          # AS/centralized_five_robots_implementation.py:174-182,300-303
+    "tb3_two_collision_free":           (2, 100, 0.02, dict(_PAIR, dmin=0.25)),       # AS/mpc_online_casadi_tb3_two_centralized_collision_free.py:80-88,180-182
+    "tb3_five_collision_free":          (5, 70, 0.02, dict(_PAIR, dmin=0.3)),         # AS/mpc_online_casadi_tb3_multi_centralized_collision_free.py:115-123,241-244
+    "tb3_six_collision_free":           (6, 35, 0.2, dict(_PAIR, dmin=0.3)),          # AS/mpc_online_casadi_tb3_six_multi_centralized_collision_free.py:127-135,279-282
+    "tb3_eight_collision_free":         (8, 5, 0.02, dict(_PAIR, dmin=0.25)),         # AS/mpc_online_casadi_tb3_eight_multi_centralized_collision_free.py:148-156,329-332
+    "mpc_online_casadi":                (1, 50, 0.01, dict(_SOLO)),                   # AS/mpc_online_casadi.py:56-61,129-131
+    "mpc_online_casadi_tb3_1":          (1, 200, 0.01, dict(_SOLO)),                  # AS/mpc_online_casadi_tb3_1.py:56-61,129-131 (tb3_2, tb3_3: same literals)
+    "casadi_test":                      (1, 25, 0.25, dict(_SOLO)),                   # AS/casadi_test.py:34-39,107-109
+    "casadi_test_mpc":                  (1, 50, 0.02, dict(_SOLO)),                   # AS/casadi_test_mpc.py:56-61,129-131
+    "first_scenario_obstacle":          (1, 100, 0.1, dict(_OBS, obstacles=[(0.4, 1.1, 0.15)])),   # AS/first_scenario_mpc_obstacle_avoidance.py:56-63,97-99,150
+    "second_scenario_obstacles":        (1, 100, 0.1, dict(_OBS, obstacles=[(1.0, 0.5, 0.15), (-0.75, 0.0, 0.125),
+                                                                          (0.0, -1.25, 0.15), (0.0, 1.0, 0.125)])),  # AS/second_scenario_mpc_obstacle_avoidance.py:56-63,97-111,164
+}
+_NAMED = {
+    "centralized_one_robot": centralized_one_robot, "centralized_two_robots": centralized_two_robots,
+    "centralized_six_robots": centralized_six_robots, "two_robots_no_collision_rows": two_robots_no_collision_rows,
+    "ten_robots_collision_avoidance": ten_robots_collision_avoidance, "third_scenario_obstacles": third_scenario_obstacles,
+}
+
+
+def script_names() -> List[str]:
+    """Every reference script (of those that build the CasADi NLP of SURVEY 8) that has a preset."""
+    return sorted(list(_SCRIPT_TABLE) + list(_NAMED))
+
+
+def script_preset(name: str, N: int = None) -> ProblemConfig:
+    """ProblemConfig holding the literals of reference script `name` (see `script_names()`); `N` overrides
+    the file's own horizon.  Unknown names raise KeyError listing the known ones."""
+    if name in _NAMED:
+        return _NAMED[name]() if N is None else _NAMED[name](N)
+    if name not in _SCRIPT_TABLE:
+        raise KeyError(f"no preset {name!r}; known: {', '.join(script_names())}")
+    m, n_file, T, kw = _SCRIPT_TABLE[name]
+    kw = dict(kw)
+    if "obstacles" in kw:
+        kw["obstacles"] = list(kw["obstacles"])
+    return ProblemConfig(m=m, N=n_file if N is None else N, T=T, **kw)

@@ -74,3 +74,11 @@ def closed_loop_oracle(ocfg, x0, goals, max_steps, stop_tol=5e-2, max_iter=2000)
     late = (err <= stop_tol) & (gi == G - 1) & ~arrived
     arrival[late] = steps; arrived |= late
     return dict(steps=steps, arrived=arrived, arrival_step=arrival, final_error=err, states=np.stack(states))
+
+
+def to_oracle_cfg(pcfg):
+    """product ProblemConfig -> oracle NLPConfig (for the script presets, whose literals tests/test_abi_host.py checks
+    against its own table)."""
+    return R.NLPConfig(m=pcfg.m, N=pcfg.N, T=pcfg.T, dmin=pcfg.dmin, q=tuple(pcfg.q), r=tuple(pcfg.r), v_max=pcfg.v_max, w_max=pcfg.w_max,
+                       xy_max=pcfg.xy_max, th_max=pcfg.th_max, obstacles=list(pcfg.obstacles), rob_dim=pcfg.rob_dim, margin=pcfg.margin,
+                       pad_value=pcfg.pad_value, pad_rows=pcfg.pad_rows, pair_rows=pcfg.pair_rows)

@@ -184,3 +184,53 @@ def test_bench_self_launches_ranks_and_never_reports_one_gpu_for_n(built):
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
+
+
+# (m, N, T, dmin, v_max, w_max, xy_max, K obstacles, pad rows) typed here from the scripts, independently of problem.py's table
+_SCRIPT_LITERALS = {
+    "first_scenario": (1, 100, 0.05, 0.0, 0.22, 2.84, 10.0, 0, False), "second_scenario": (2, 50, 0.1, 0.25, 0.22, 2.84, 10.0, 0, True),
+    "third_scenario": (3, 50, 0.05, 0.3, 0.22, 2.84, 10.0, 0, True), "fourth_scenario": (4, 50, 0.1, 0.3, 0.22, 2.84, 10.0, 0, True),
+    "fifth_scenario": (5, 35, 0.1, 0.3, 0.22, 2.84, 10.0, 0, True), "sixth_scenario": (6, 35, 0.3, 0.3, 0.22, 2.84, 10.0, 0, True),
+    "decentralized_first_scenario": (1, 200, 0.05, 0.0, 0.22, 2.84, 2.0, 0, False),
+    "decentralized_two_robots": (2, 50, 0.1, 0.25, 0.22, 2.84, 10.0, 0, True),
+    "centralized_one_robot": (1, 100, 0.05, 0.0, 0.22, 2.84, 10.0, 0, False), "centralized_two_robots": (2, 70, 0.05, 0.15, 0.22, 2.84, 10.0, 0, True),
+    "centralized_three_robots": (3, 60, 0.05, 0.15, 0.22, 2.84, 10.0, 0, True), "centralized_four_robots": (4, 45, 0.1, 0.4, 0.22, 2.84, 10.0, 0, True),
+    "centralized_five_robots": (5, 40, 0.1, 0.4, 0.22, 2.84, 10.0, 0, True), "centralized_six_robots": (6, 35, 0.3, 0.4, 0.15, 1.5, 10.0, 0, True),
+    "tb3_two_collision_free": (2, 100, 0.02, 0.25, 0.22, 2.84, 10.0, 0, True), "tb3_five_collision_free": (5, 70, 0.02, 0.3, 0.22, 2.84, 10.0, 0, True),
+    "tb3_six_collision_free": (6, 35, 0.2, 0.3, 0.22, 2.84, 10.0, 0, True), "tb3_eight_collision_free": (8, 5, 0.02, 0.25, 0.22, 2.84, 10.0, 0, True),
+    "ten_robots_collision_avoidance": (10, 20, 0.1, 0.3, 0.22, 2.84, 10.0, 0, True),
+    "two_robots_no_collision_rows": (2, 50, 0.01, 0.0, 0.22, 2.84, 10.0, 0, False),
+    "mpc_online_casadi": (1, 50, 0.01, 0.0, 0.22, 2.84, 10.0, 0, False), "mpc_online_casadi_tb3_1": (1, 200, 0.01, 0.0, 0.22, 2.84, 10.0, 0, False),
+    "casadi_test": (1, 25, 0.25, 0.0, 0.22, 2.84, 10.0, 0, False), "casadi_test_mpc": (1, 50, 0.02, 0.0, 0.22, 2.84, 10.0, 0, False),
+    "first_scenario_obstacle": (1, 100, 0.1, 0.0, 0.2, np.pi / 4, 10.0, 1, False),
+    "second_scenario_obstacles": (1, 100, 0.1, 0.0, 0.2, np.pi / 4, 10.0, 4, False),
+    "third_scenario_obstacles": (1, 100, 0.2, 0.0, 0.2, 1.0, 10.0, 6, False),
+}
+
+
+def test_script_presets_hold_the_scripts_literals(built):
+    """every reference script that builds the NLP of SURVEY 8 is a parameter set of the one generic solver (SURVEY 2:
+    'scenario variants as extra parameter sets'); sizes follow the scripts' own `args` shapes."""
+    import nmpc_amd
+    from tests import helpers as Hh
+    L = nmpc_amd._lib.load()
+    assert set(nmpc_amd.script_names()) == set(_SCRIPT_LITERALS)
+    for name, (m, N, T, dmin, v, w, xy, K, pad) in _SCRIPT_LITERALS.items():
+        c = nmpc_amd.script_preset(name)
+        assert (c.m, c.N, c.T, c.dmin, c.v_max, c.xy_max, len(c.obstacles), c.pad_rows) == (m, N, T, dmin, v, xy, K, pad), name
+        assert abs(c.w_max - w) < 1e-15 and c.q == (1.0, 5.0, 0.1) and c.r == (0.5, 0.05), name
+        M = m * (m - 1) // 2 if c.pair_rows else 0
+        # the scripts' lbg: (N+1) blocks of (3m + M) rows (second_scenario.py:181), or 3 + N*(3+K) for the obstacle files
+        assert c.n_g == ((3 * m + M) * (N + 1) if K == 0 else 3 + N * (3 + K)), name
+        assert c.n_var == 3 * m * (N + 1) + 2 * m * N
+        cc = c.to_c()
+        assert L.nmpc_n_var(C.byref(cc)) == c.n_var and L.nmpc_n_g(C.byref(cc)) == c.n_g
+        oc = Hh.to_oracle_cfg(c)
+        for a, b in zip(c.bounds(), R.bounds(oc)):
+            np.testing.assert_array_equal(a, b)
+        assert nmpc_amd.script_preset(name, N=7).N == 7
+    ob = nmpc_amd.script_preset("first_scenario_obstacle")
+    assert (ob.rob_dim, ob.margin, ob.th_max) == (0.15, 0.05, 2 * np.pi) and ob.obstacles == [(0.4, 1.1, 0.15)]
+    assert nmpc_amd.script_preset("second_scenario_obstacles").obstacles[1] == (-0.75, 0.0, 0.125)
+    with pytest.raises(KeyError):
+        nmpc_amd.script_preset("no_such_script")

@@ -445,3 +445,31 @@ def test_composite_closed_loop_soak_has_no_failed_solve(built):
     print(f"composite soak: {ep.total_solves} solves, failed {ep.failed_solves}, collision-free {ep.collision_free.mean():.3f}, mean iterations {ep.mean_iters_by_step.mean():.1f}")
     assert ep.total_solves == B * 40 and ep.failed_solves == 0
     assert ep.collision_free.all()
+
+
+def _preset_names():
+    import importlib
+    return importlib.import_module("nmpc_amd").script_names()
+
+
+@pytest.mark.parametrize("name", _preset_names())
+def test_every_script_preset_matches_oracle(built, name):
+    """each reference script that builds this NLP, at the file's own horizon and literals (nmpc_amd.script_preset),
+    solved on a seeded batch of 8 and compared with the oracle given the same literals."""
+    import torch
+    import nmpc_amd
+    pcfg = nmpc_amd.script_preset(name)
+    pcfg.max_iter = 600
+    ocfg = Hh.to_oracle_cfg(pcfg)
+    B = 8
+    P, W0 = Hh.batch(ocfg, B, 40 + sorted(_preset_names()).index(name))
+    s = nmpc_amd.NmpcSolver(pcfg, max_batch=B)
+    r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+    ref = O.solve_batch(O.make_config(ocfg, max_iter=600), P, W0)
+    assert (r["status"] == ref["status"]).all(), (r["status"], ref["status"])
+    conv = r["status"] == 0
+    assert conv.mean() >= 0.87, r["status"]
+    dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
+    print(f"{name}: m={pcfg.m} N={pcfg.N} same-basin {(dw[conv] <= W_TOL).mean():.3f}, iters hip {r['iters'].mean():.1f} oracle {ref['iters'].mean():.1f}")
+    assert (dw[conv] <= W_TOL).mean() >= 0.87, dw
+    np.testing.assert_allclose(r["f"][conv & (dw <= W_TOL)], ref["f"][conv & (dw <= W_TOL)], rtol=F_RTOL, atol=1e-9)
