@@ -6,15 +6,15 @@
 //         [ Qxu Qxx | qx ]
 // is spread element-per-lane and every pivot step goes through LDS twice (publish the pivot row, gather two factors per
 // element).  Here ONE LANE OWNS ONE COLUMN and keeps all of its rows in registers (m[r], r = 0..NZ-1, plus the right-hand side
-// as row NZ), state column s on lane s, control column a on lane 32 + a, so that a whole stage needs no LDS traffic for the
+// as row NZ), state column s on lane s, control column a on lane NX + a, so that a whole stage needs no LDS traffic for the
 // matrix at all:
 //   * P_k+1 is simply what the previous stage left in rows NU.. of the state lanes; P c_k is NX FMAs with broadcast defects;
 //   * G = P [B A] is a lane gather of at most two foreign columns per lane (ds_bpermute, <= 3 terms per column) and
 //     [B A]^T G is a ROW operation, i.e. a handful of in-lane FMAs with wave-uniform coefficients per robot;
 //   * the Hessian additions arrive through per-lane LDS offsets into the staged pack (fixed per sweep);
 //   * a pivot step is  m[a] -= M[j][a] * (m[j] / d_j)  for all remaining rows a: the multiplier M[j][a] sits in lane L(a) of
-//     register m[j] and is fetched with v_readlane into an SGPR pair (symmetry), so the update is one v_fma_f64 per row with a
-//     scalar operand — no LDS round trip, no wave synchronisation, all 64 lanes of the FMA useful work on full storage;
+//     register m[j] (symmetry) and is broadcast by the DPP operand of the multiply-add itself (v_fmac_f64_dpp row_newbcast),
+//     one DP instruction per row — no LDS round trip, no wave synchronisation, no scalar round trip;
 //   * pivot rows and reciprocal pivots stream to HBM/L2 in the layout the forward sweep of nmpc_solve_lds.hip reads.
 // One wavefront per swarm instance for every team size (ten robots: 50 of 64 lanes, 51 rows = 102 VGPRs).
 #include "nmpc_solve_common.h"
@@ -25,13 +25,36 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-// rows below this index fetch their elimination multiplier with v_readlane, the others from the LDS broadcast of the pivot row
-#ifndef NMPC_RL_SPLIT
-#define NMPC_RL_SPLIT(NU_, NZ_) (NZ_)
+// Elimination multipliers.  NMPC_COL_DPP=1 (default): the multiplier of row a, lane LC(a) of the pivot row register, reaches
+// every lane INSIDE the multiply-add: v_fmac_f64_dpp ... row_newbcast:n reads lane n of the executing lane's own row of 16
+// lanes, so one DP instruction per row replaces v_readlane x2 + v_fma_f64.  Teams whose NZ columns span several rows of 16
+// first replicate each row of the pivot register into the other rows (v_permlane16_swap / v_permlane32_swap, gfx950),
+// 4 (two rows) or 12 (four rows) 32-bit VALU moves per pivot step.  NMPC_COL_DPP=0 keeps the readlane form (A/B).
+// tools/dpp_probe.hip checks the lane semantics of both instructions on the device.
+#ifndef NMPC_COL_DPP
+#define NMPC_COL_DPP 1
 #endif
 
-// lane that owns column c of the augmented matrix: state column NU + s on lane s, control column a on lane 32 + a
-#define LC(c) (((c) < NU) ? 32 + (c) : (c) - NU)
+// lane that owns column c of the augmented matrix: state column NU + s on lane s, control column a on lane NX + a
+#define LC(c) (((c) < NU) ? NX + (c) : (c) - NU)
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int N_> __device__ __forceinline__ void fmac_rowb(double &acc, double u, double nr)      // acc += u[lane N_ of my row of 16] * nr
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(nr), "n"(N_));
+}
+__device__ __forceinline__ void swap16(double &a, double &b)      // odd rows (of 16 lanes) of a <-> even rows of b
+{
+    u32x2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    u32x2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi.x, lo.x); b = __hiloint2double(hi.y, lo.y);
+}
+__device__ __forceinline__ void swap32(double &a, double &b)      // upper 32 lanes of a <-> lower 32 lanes of b
+{
+    u32x2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    u32x2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi.x, lo.x); b = __hiloint2double(hi.y, lo.y);
+}
 
 __device__ __forceinline__ double lane_gather(int src4, double v)     // v of lane src4 / 4
 {
@@ -48,7 +71,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     constexpr int TPB = 64;
     constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
-    static_assert(NX <= 32 && NU <= 32, "state columns live on lanes 0..31, control columns on lanes 32..63");
+    static_assert(NZ <= 64, "one lane per column of the augmented matrix");
+    constexpr int NR = (NZ + 15) / 16;     // rows of 16 lanes that hold columns
     const int tid = threadIdx.x;
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
@@ -72,7 +96,6 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     constexpr int RG0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     double *XS = RV + ((N1 * NX > RG0) ? N1 * NX : RG0);   // [NX]
     double *RED = XS + NX;                // [8]
-    double *BR = RED + 8;                 // [2][64]  (only when NMPC_RL_SPLIT < NZ) pivot row of the current / previous pivot step, one entry per lane
     double *gd = ws + inst * P.stride2 + P.oDUAL;
     double *SPp = gd;                     // [N1*NP]   pair slacks
     double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
@@ -101,9 +124,9 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     auto bvl = [&](int s) { return (THB && (s % 3 == 2)) ? P.thmax : P.xymax; };
 
     // ---- column ownership: lane -> column of the augmented matrix (controls 0..NU-1, states NU..NZ-1)
-    const bool is_state = tid < NX, is_ctrl = tid >= 32 && tid < 32 + NU, lvalid = is_state || is_ctrl;
+    const bool is_state = tid < NX, is_ctrl = tid >= NX && tid < NZ, lvalid = tid < NZ;
     const int ms = is_state ? tid : 0;                       // my state index
-    const int ma = is_ctrl ? tid - 32 : 0;                   // my control index
+    const int ma = is_ctrl ? tid - NX : 0;                   // my control index
     const int mycol = is_state ? NU + ms : ma;               // 0 on unused lanes (they carry zero coefficients)
     const int mrob = is_state ? ms / 3 : ma >> 1;
     // gather sources of G = P [B A]: at most two foreign columns per lane
@@ -595,9 +618,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 static_for<0, NZ>([&](auto rc) { constexpr int r = decltype(rc)::value; m[r] += lds_ld(PK, hoff[r], 0); });
                 m[NZ] += lds_ld(PK, goff, 0);
                 PROF_T(10);
-                // ---- 5. NU pivot steps.  Row a loses M[j][a] / d_j times the pivot row; M[j][a] is lane L(a) of m[j] (symmetry): the
-                //      pivot row goes to LDS once (one entry per lane) and every lane reads the multipliers of all remaining rows back
-                //      as broadcasts (uniform addresses, two rows per ds_read_b128), so the updates are plain VGPR FMAs
+                // ---- 5. NU pivot steps.  Row a loses M[j][a] / d_j times the pivot row; M[j][a] is lane L(a) of m[j] (symmetry) and is
+                //      broadcast inside the multiply-add (row_newbcast DPP operand), one DP instruction per remaining row
                 double d0s[NU];                          // the control diagonals as assembled (pivot test reference), wave-uniform
                 static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; d0s[j] = lane_read(m[j], LC(j)); });
                 auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0) && d > 0.0) ? rcp_nr(d) : -1.0; };
@@ -609,32 +631,40 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                         const double inv = inv_cur;
                         if (!(inv > 0.0)) ok = false;
                         else {
-                            // multipliers M[j][a], a > j: rows a < RL_SPLIT through v_readlane (2 VALU instructions each, the SIMD's own
-                            // pipe), rows a >= RL_SPLIT through one LDS broadcast of the pivot row (uniform-address ds_read_b128, two rows
-                            // each, the pipe the four SIMDs of a CU share).  Measured (A/B in one session): all-readlane wins at
-                            // every team size (six robots 117 k vs 101 k solves/s, ten robots 39.4 k vs 34.4 k); a ds_bpermute with a uniform
-                            // source lane (no LDS write, no wait) is slower still (ten robots 23 k)
-                            constexpr int RL_SPLIT = NMPC_RL_SPLIT(NU, NZ);
-                            double *br = BR + (j & 1) * 64;
-                            if constexpr (RL_SPLIT < NZ) br[tid] = m[j];
                             if (lvalid) gkt[(size_t)k * G::KTS + j * LD + mycol] = m[j];      // pivot row j as the forward sweep reads it
                             const double rhs_j = lane_read(m[NZ], LC(j));
                             invv = (tid == j) ? inv : invv; rhsv = (tid == j) ? rhs_j : rhsv;
                             const double rjv = m[j] * inv;
-                            if constexpr (RL_SPLIT < NZ) lds_sync<TPB>();
-                            auto mult = [&](auto ac) {
+#if NMPC_COL_DPP
+                            // the pivot row register, each of its rows of 16 lanes replicated into all rows (ur[r] = row r everywhere)
+                            double ur[NR < 3 ? NR : 4];
+                            if constexpr (NR == 1) asm("s_nop 4" : "+v"(m[j]));      // (see below; in place, no copy of the register)
+                            ur[0] = m[j];
+                            if constexpr (NR == 2) { ur[1] = m[j]; swap16(ur[0], ur[1]); }
+                            if constexpr (NR >= 3) {
+                                ur[1] = m[j]; swap16(ur[0], ur[1]);
+                                ur[2] = ur[0]; swap32(ur[0], ur[2]);
+                                ur[3] = ur[1]; swap32(ur[1], ur[3]);
+                            }
+                            double nrjv = -rjv;
+                            // VALU write -> DPP read of the same VGPR needs 2 wait states, an EXEC write 5; hipcc does not look into asm
+                            if constexpr (NR >= 2) { asm("s_nop 4" : "+v"(ur[0])); asm("s_nop 0" : "+v"(ur[1])); }
+                            if constexpr (NR >= 3) { asm("s_nop 0" : "+v"(ur[2])); asm("s_nop 0" : "+v"(ur[3])); }
+                            auto elim = [&](auto ac) {
                                 constexpr int a = decltype(ac)::value;
-                                if constexpr (a < RL_SPLIT) return lane_read(m[j], LC(a));
-                                else return br[LC(a)];
+                                fmac_rowb<(LC(a) & 15)>(m[a], ur[LC(a) >> 4], nrjv);
                             };
+#else
+                            auto elim = [&](auto ac) {
+                                constexpr int a = decltype(ac)::value;
+                                m[a] = fma(-lane_read(m[j], LC(a)), rjv, m[a]);
+                            };
+#endif
                             if constexpr (j + 1 < NU) {       // the next pivot row first: its reciprocal overlaps the other rows
-                                m[j + 1] = fma(-mult(std::integral_constant<int, j + 1>{}), rjv, m[j + 1]);
+                                elim(std::integral_constant<int, j + 1>{});
                                 inv_cur = pivot_inv(lane_read(m[j + 1], LC(j + 1)), d0s[j + 1]);
                             }
-                            static_for<(j + 1 < NU ? j + 2 : j + 1), NZ>([&](auto ac) {
-                                constexpr int a = decltype(ac)::value;
-                                m[a] = fma(-mult(ac), rjv, m[a]);
-                            });
+                            static_for<(j + 1 < NU ? j + 2 : j + 1), NZ>([&](auto ac) { elim(ac); });
                             m[NZ] = fma(-rhs_j, rjv, m[NZ]);
                         }
                     }
@@ -989,7 +1019,7 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P)
     (void)MK;
     const size_t rg0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     d += (N1 * G::NX > rg0) ? N1 * G::NX : rg0;
-    d += G::NX + 8 + (NMPC_RL_SPLIT(G::NU, G::NZ) < G::NZ ? 128 : 0);
+    d += G::NX + 8;
     return d * sizeof(double);
 }
 
