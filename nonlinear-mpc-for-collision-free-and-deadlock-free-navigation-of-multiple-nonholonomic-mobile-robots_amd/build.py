@@ -27,7 +27,7 @@ def source_hash() -> str:
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode()); h.update(f.read())
-    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_RL_SPLIT", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION"):
+    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_RL_SPLIT", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
         h.update((k + "=" + os.environ.get(k, "")).encode())
     return h.hexdigest()[:16]
 
@@ -58,6 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="%s"' % source_hash()]
     if os.environ.get("NMPC_PROFILE"):
         flags.append("-DNMPC_PROFILE")
+    flags += os.environ.get("NMPC_EXTRA_DEFS", "").split()      # development: extra -D switches of experiments (A/B)
     if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30
         flags.append("-DNMPC_POISON=" + os.environ["NMPC_POISON"])
     if os.environ.get("NMPC_RL_SPLIT"):       # development: e.g. NMPC_RL_SPLIT="(NU_)" or "((NU_)+9)"

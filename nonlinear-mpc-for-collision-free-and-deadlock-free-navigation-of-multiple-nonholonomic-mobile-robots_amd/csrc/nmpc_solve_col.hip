@@ -31,6 +31,12 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 // first replicate each row of the pivot register into the other rows (v_permlane16_swap / v_permlane32_swap, gfx950),
 // 4 (two rows) or 12 (four rows) 32-bit VALU moves per pivot step.  NMPC_COL_DPP=0 keeps the readlane form (A/B).
 // tools/dpp_probe.hip checks the lane semantics of both instructions on the device.
+#ifndef NMPC_COL_GB
+#define NMPC_COL_GB 32       // rows per batch of the G = P [B A] gathers (32 = all at once; development knob)
+#endif
+#ifndef NMPC_FW_FAKE
+#define NMPC_FW_FAKE 0       // development: 1 = the forward sweep re-reads stage 0's rows (wrong results; separates compute from memory time)
+#endif
 #ifndef NMPC_COL_DPP
 #define NMPC_COL_DPP 1
 #endif
@@ -576,6 +582,10 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
             double pkr[PKR];
 #pragma unroll
             for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            // the last pivot row and the right-hand sides of a stage are stored at the top of the NEXT stage, behind the wait for that
+            // stage's pack: vmcnt counts loads and stores in order, so a store issued just before the wait adds its whole
+            // acknowledgement latency to it
+            double pend_row = 0.0, pend_rhs = 0.0;
             for (int k = N - 1; k >= 0; k--) {
                 // ---- stage pack -> LDS (the inertia shift delta joins the control diagonal here); prefetch the next one
                 lds_sync<TPB>();         // every read of the previous stage's pack is done
@@ -589,6 +599,11 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                     for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
                 }
                 lds_sync<TPB>();
+                double *const gkrow = gkt + (size_t)k * G::KTS + (lvalid ? mycol : NZ + 1);
+                if (k < N - 1) {
+                    gkrow[G::KTS + (NU - 1) * G::LDC] = pend_row;
+                    if (tid < NU) gkt[(size_t)(k + 1) * G::KTS + tid * G::LDC + NZ] = pend_rhs;
+                }
                 // coefficients of the <= 3 terms of my column of [B A]: own, gathered A, gathered B
                 double kO, kA, kB;
                 {
@@ -599,9 +614,15 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 static_for<0, NX>([&](auto sc) { constexpr int s = decltype(sc)::value; m[NZ] = fma(-m[NU + s], PK[G::PK_C + s], m[NZ]); });
                 // ---- 2. G = P [B A] (and the same combination of the right-hand side): own column + two gathered columns
                 {
-                    double tA[NX + 1], tB[NX + 1];      // all gathers first (one LDS-crossbar latency for the stage, not one per row)
-                    static_for<0, NX + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q] = lane_gather(srcA, m[NU + q]); tB[q] = lane_gather(srcB, m[NU + q]); });
-                    static_for<0, NX + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NU + q] = fma(kB, tB[q], fma(kA, tA[q], kO * m[NU + q])); });
+                    // gathers in batches of GB rows, all of a batch before its first use: one LDS-crossbar latency per batch, and
+                    // no more than 2 GB gathered values alive next to the matrix (register budget of two waves per SIMD)
+                    constexpr int GB = NMPC_COL_GB;
+                    static_for<0, (NX + 1 + GB - 1) / GB>([&](auto bc) {
+                        constexpr int q0 = decltype(bc)::value * GB, q1 = (q0 + GB < NX + 1) ? q0 + GB : NX + 1;
+                        double tA[GB], tB[GB];
+                        static_for<q0, q1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q - q0] = lane_gather(srcA, m[NU + q]); tB[q - q0] = lane_gather(srcB, m[NU + q]); });
+                        static_for<q0, q1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NU + q] = fma(kB, tB[q - q0], fma(kA, tA[q - q0], kO * m[NU + q])); });
+                    });
                 }
                 PROF_T(9);
                 // ---- 3. [B A]^T G: a row operation, i.e. in-lane, with the wave-uniform coefficients of each robot
@@ -624,17 +645,26 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; d0s[j] = lane_read(m[j], LC(j)); });
                 auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0) && d > 0.0) ? rcp_nr(d) : -1.0; };
                 double inv_cur = pivot_inv(d0s[0], d0s[0]);
-                double invv = 0.0, rhsv = 0.0;           // lane j <- reciprocal pivot j, right-hand side of pivot row j
+                double rhsv = 0.0;                       // lane j <- right-hand side of pivot row j, times -1/pivot
                 static_for<0, NU>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     if (ok) {
                         const double inv = inv_cur;
                         if (!(inv > 0.0)) ok = false;
                         else {
-                            if (lvalid) gkt[(size_t)k * G::KTS + j * LD + mycol] = m[j];      // pivot row j as the forward sweep reads it
                             const double rhs_j = lane_read(m[NZ], LC(j));
-                            invv = (tid == j) ? inv : invv; rhsv = (tid == j) ? rhs_j : rhsv;
+                            rhsv = (tid == j) ? -rhs_j * inv : rhsv;
                             const double rjv = m[j] * inv;
+                            double nrjv = -rjv;
+                            // pivot row j as the forward sweep wants it: times -1/pivot, zero up to the diagonal.  Every lane stores (the
+                            // lanes without a column share the padding slot of the row); the comparison is made here, from an opaque copy
+                            // of the column index: hoisted out of the sweep its 12 masks are spilled and reloaded lane by lane
+                            {
+                                int mc = mycol;
+                                asm("" : "+v"(mc));
+                                if constexpr (j == NU - 1) pend_row = (mc > j) ? nrjv : 0.0;
+                                else gkrow[j * G::LDC] = (mc > j) ? nrjv : 0.0;
+                            }
 #if NMPC_COL_DPP
                             // the pivot row register, each of its rows of 16 lanes replicated into all rows (ur[r] = row r everywhere)
                             double ur[NR < 3 ? NR : 4];
@@ -646,8 +676,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                                 ur[2] = ur[0]; swap32(ur[0], ur[2]);
                                 ur[3] = ur[1]; swap32(ur[1], ur[3]);
                             }
-                            double nrjv = -rjv;
-                            // VALU write -> DPP read of the same VGPR needs 2 wait states, an EXEC write 5; hipcc does not look into asm
+                            // VALU write -> DPP read of the same VGPR needs 2 wait states (no VALU writes EXEC here); hipcc does not look into asm
                             if constexpr (NR >= 2) { asm("s_nop 4" : "+v"(ur[0])); asm("s_nop 0" : "+v"(ur[1])); }
                             if constexpr (NR >= 3) { asm("s_nop 0" : "+v"(ur[2])); asm("s_nop 0" : "+v"(ur[3])); }
                             auto elim = [&](auto ac) {
@@ -671,8 +700,12 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 });
                 PROF_T(11);
                 if (!ok) break;
-                // reciprocal pivots and the right-hand sides of the pivot rows (lanes 0..NU-1 hold them)
-                if (tid < NU) { gkt[(size_t)k * G::KTS + NU * LD + tid] = invv; gkt[(size_t)k * G::KTS + tid * LD + NZ] = rhsv; }
+                // the right-hand sides of the pivot rows (lanes 0..NU-1 hold them)
+                pend_rhs = rhsv;
+                if (k == 0) {
+                    gkrow[(NU - 1) * G::LDC] = pend_row;
+                    if (tid < NU) gkt[tid * G::LDC + NZ] = pend_rhs;
+                }
                 // what is left in rows NU.. of the state lanes is [P_k | p_k]
             }
             if (ok) break;
@@ -687,11 +720,84 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
         __syncthreads();   // s_waitcnt vmcnt(0): the stage-0 gains were stored a moment ago by other lanes of this wave
         PROF_T(3);
 
-        // ============ C. forward sweep.  The stage factors stream back from HBM/L2 through a register ring filled PD stages
-        // ahead by all threads (coalesced), then through an LDS staging buffer (the pivot-row area, free here).  Per stage the control
-        // lanes form t = Uux dx + rhs and solve Uuu du = -t by back substitution with v_readlane broadcasts.
-        {
-            constexpr int KPT = (G::KTS + TPB - 1) / TPB, PD = 4;
+        // ============ C. forward sweep: du_k = -(t + Uuu' du), t = rhs' + Uux' dx_k with the pivot rows as stored (times -1/pivot),
+        // then dx_{k+1} = A dx_k + B du_k - c_k per robot.
+        // Teams with NU <= 16: no LDS staging and no scalar round trips.  Three lane roles, one register each:
+        //   S (lane r < NX)        holds dx[r]; updates its own state with its robot's (a, b, c) coefficients
+        //   T (lane 16 + j)        holds the state part and the right-hand side of pivot row j: t_j = sum_c bcast(dx_c) * row[c],
+        //                          NX multiply-adds whose DPP operand is dx (its rows of 16 lanes replicated by v_permlane16_swap)
+        //   B (lane 48 + j)        holds the control part of pivot row j (zero up to the diagonal): back substitution, step c
+        //                          adds bcast(du_c) * row[c] to every later row's accumulator — one multiply-add per control
+        // Each T / B lane loads ITS row straight from HBM/L2 into registers (dwordx4, PD stages ahead).
+        if constexpr (NU <= 16 && NX <= 32) {
+            constexpr int LDC = G::LDC, CT = (NX + 3) & ~1, CH = CT / 2, PD = 2;
+            static_assert(NU + CT <= LDC && NU <= CT, "row chunks of the forward sweep");
+            const bool isT = tid >= 16 && tid < 16 + NU, isB = tid >= 48 && tid < 48 + NU;
+            const double2 *rowp = reinterpret_cast<const double2 *>(gkt + (isT ? (tid - 16) * LDC + NU : (isB ? (tid - 48) * LDC : NU)));
+            double kq[PD][CT];
+            auto fetch = [&](auto dc, int k) {
+                constexpr int d = decltype(dc)::value;
+#pragma unroll
+                for (int t = 0; t < CH; t++) {      // every lane loads (the lanes without a role read what lane 16 reads): no exec-masked regions
+                    const double2 v = rowp[(size_t)(NMPC_FW_FAKE ? 0 : k) * (G::KTS / 2) + t];
+                    kq[d][2 * t] = v.x; kq[d][2 * t + 1] = v.y;
+                }
+            };
+            static_for<0, PD>([&](auto dc) { if (decltype(dc)::value < N) fetch(dc, decltype(dc)::value); });
+            double dx = 0.0;
+            if (is_state) DX[tid] = 0.0;
+            for (int k0 = 0; k0 < N; k0 += PD) {
+                static_for<0, PD>([&](auto dc) {
+                    constexpr int d = decltype(dc)::value;
+                    const int k = k0 + d;
+                    if (k < N) {
+                        // lane constants rebuilt from the lane id per stage (a handful of integer operations): kept across the loop they are
+                        // spilled, and a spill reload inside the loop waits (vmcnt is in order) for the row prefetches in flight
+                        int ln = tid;
+                        asm volatile("" : "+v"(ln));
+                        const int fr = ln < NX ? ln : 0, fi = fr / 3, fd = fr - 3 * fi;
+                        const int srcT = 4 * (3 * fi + 2), srcU = 4 * (48 + (fd < 2 ? 2 * fi : 2 * fi + 1));
+                        // coefficients of my state's row of [A B | c] (independent of the recursion: issued first)
+                        const double sn = SN[k * M_ + fi], cs = CS[k * M_ + fi], uv = U[k * NU + 2 * fi], uw = U[k * NU + 2 * fi + 1];
+                        const double xk = X[k * NX + fr], xn = X[(k + 1) * NX + fr];
+                        const double dxt = lane_gather(srcT, dx);
+                        double u0 = dx, u1 = dx;
+                        swap16(u0, u1);                   // u0 = lanes 0..15 of dx in both rows of each half, u1 = lanes 16..31 (the T lanes sit in row 1)
+                        asm("s_nop 4" : "+v"(u0));
+                        if constexpr (NX > 16) asm("s_nop 0" : "+v"(u1));
+                        double t = kq[d][NX];
+                        static_for<0, NX>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            if constexpr (c < 16) fmac_rowb<(c & 15)>(t, u0, kq[d][c]);
+                            else fmac_rowb<(c & 15)>(t, u1, kq[d][c]);
+                        });
+                        double tb = t, tl = t;
+                        swap32(tb, tl);                   // lanes 48 + j <- t of lanes 16 + j
+                        static_for<1, NU>([&](auto cc) {
+                            constexpr int c = NU - decltype(cc)::value;      // NU-1 .. 1: du_c is final on lane 48 + c when its turn comes
+                            asm("s_nop 1" : "+v"(tb));
+                            double ub = tb;
+                            fmac_rowb<c>(tb, ub, kq[d][c]);
+                        });
+                        if (ln >= 48 && ln < 48 + NU) DU[k * NU + (ln - 48)] = tb;
+                        const double du = lane_gather(srcU, tb);
+                        if (k + PD < N) fetch(dc, k + PD);
+                        // dx+ = dx + a dx_theta + b du - c:  x: a = -T v sin, b = T cos;  y: a = T v cos, b = T sin;  theta: a = 0, b = T
+                        const double Tv = T * uv;
+                        const double ca = (fd == 0) ? -Tv * sn : ((fd == 1) ? Tv * cs : 0.0);
+                        const double cb = (fd == 0) ? T * cs : ((fd == 1) ? T * sn : T);
+                        const double dfc = (fd == 2) ? defect_th(xn, xk, T, uw) : defect_xy(xn, xk, Tv, (fd == 0) ? cs : sn);
+                        dx = fma(cb, du, fma(ca, dxt, dx)) - dfc;
+                        if (ln < NX) DX[(k + 1) * NX + ln] = dx;
+                    }
+                });
+            }
+            __syncthreads();
+        } else {
+            // larger teams: the stage factors stream back through a register ring filled PD stages ahead by all lanes (coalesced),
+            // then through an LDS staging buffer (the pack area, free here); the control lanes form t and substitute back with
+            // v_readlane broadcasts
+            constexpr int KPT = (G::KTS + TPB - 1) / TPB, PD = 4, LDC = G::LDC;
             double kq[PD][KPT];
 #pragma unroll
             for (int d = 0; d < PD; d++)
@@ -711,8 +817,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                             for (int t = 0; t < KPT; t++) { int e = tid + t * TPB; if (e < G::KTS) kq[d][t] = gkt[(size_t)(k + PD) * G::KTS + e]; }
                         }
                         lds_sync<TPB>();
-                        if (tid < 64) {      // the NU control lanes live in the first wave
-                            const double *row = FS + jrow * LD;
+                        {
+                            const double *row = FS + jrow * LDC;
                             double t0 = row[NZ], t1 = 0.0, t2 = 0.0;
 #pragma unroll
                             for (int c = 0; c + 2 < NX; c += 3) {
@@ -721,18 +827,15 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                                 t2 = fma(row[NU + c + 2], DX[k * NX + c + 2], t2);
                             }
                             double tj = t0 + (t1 + t2);
-                            const double invj = FS[NU * LD + jrow];
                             double urow[NU];
 #pragma unroll
                             for (int c = 0; c < NU; c++) urow[c] = row[c];
                             double duj = 0.0;
                             static_for<0, NU>([&](auto cc) {
                                 constexpr int c = NU - 1 - decltype(cc)::value;
-                                const double cand = -tj * invj;            // meaningful on lane c: all its later columns are in
-                                const double duc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cand), c),
-                                                                    __builtin_amdgcn_readlane(__double2loint(cand), c));
+                                const double duc = lane_read(tj, c);       // final on lane c: all its later columns are in
                                 if (tid == c) duj = duc;
-                                tj = fma(urow[c], duc, tj);                // rows j < c use it; rows j >= c are done (their tj is dead)
+                                tj = fma(urow[c], duc, tj);                // rows j < c use it (urow[c] is zero for rows j >= c)
                             });
                             if (tid < NU) DU[k * NU + tid] = duj;
                         }

@@ -32,7 +32,11 @@ template <int M_, int THB> struct G2 {
     static constexpr int diag_e(int j) { int e = 0; for (int a = 0; a < j; a++) e += NZ - a + 1; return e; }   // flat index of element (j,j)
     static constexpr int slice_lo(int t, int tpb) { return row_of(t * tpb); }
     static constexpr int slice_hi(int t, int tpb) { return row_of((t * tpb + tpb - 1 < NT) ? (t * tpb + tpb - 1) : (NT - 1)); }
-    static constexpr int KTS = (NU * LD + NU + 7) / 8 * 8;      // per stage: the NU pivot rows [Uuu | Uux | rhs] and the NU reciprocal pivots
+    // per stage: the NU pivot rows.  Element-per-lane kernel: [Uuu | Uux | rhs] at row stride LD, then the NU reciprocal pivots.
+    // Column-per-lane kernel: the rows scaled by -1/pivot, [-Uuu/d (strictly upper part, else 0) | -Uux/d | -rhs/d | pad] at the
+    // even row stride LDC (16-byte aligned rows: the forward sweep loads its row with dwordx4)
+    static constexpr int LDC = (NZ + 3) & ~1;
+    static constexpr int KTS = ((NU * LD + NU > NU * LDC ? NU * LD + NU : NU * LDC) + 7) / 8 * 8;
 };
 
 // ---- single evaluation points.  Constraint values, slack steps and defects are recomputed at several places of an
