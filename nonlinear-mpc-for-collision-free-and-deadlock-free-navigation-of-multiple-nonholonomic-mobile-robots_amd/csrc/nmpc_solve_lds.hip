@@ -210,9 +210,10 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     auto merit = [&](double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
         double fs = 0.0, l = 0.0, t = 0.0, mc = 0.0, mh = 0.0;
         // one bound row: current slack sv, current value h0, step of the value jd, trial value ht
+        double pr = 1.0;       // product of the slacks of one (stage, robot) item: one logarithm per item (see nmpc_solve_col.hip)
         auto brow = [&](double sv, double h0, double jd, double ht) {
             double st = sv + a * (jd + (h0 - sv));
-            l += log(st);
+            pr *= st;
             double r = fabs(ht - st);
             t += r; mh = fmax(mh, r);
         };
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             brow(SUL[ou], U[ou] + P.vmax, DU[ou], u0 + P.vmax); brow(SUU[ou], P.vmax - U[ou], -DU[ou], P.vmax - u0);
             brow(SUL[ou + 1], U[ou + 1] + P.wmax, DU[ou + 1], u1 + P.wmax); brow(SUU[ou + 1], P.wmax - U[ou + 1], -DU[ou + 1], P.wmax - u1);
             // state bounds of stage k+1
-            l += log(n0 + P.xymax) + log(P.xymax - n0) + log(n1 + P.xymax) + log(P.xymax - n1);
-            if (THB) l += log(n2 + P.thmax) + log(P.thmax - n2);
+            pr *= ((n0 + P.xymax) * (P.xymax - n0)) * ((n1 + P.xymax) * (P.xymax - n1));
+            if (THB) pr *= (n2 + P.thmax) * (P.thmax - n2);
+            l += log(pr);
+            pr = 1.0;
         }
         for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
