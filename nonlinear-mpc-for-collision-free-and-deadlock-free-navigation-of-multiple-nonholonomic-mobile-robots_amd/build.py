@@ -27,7 +27,7 @@ def source_hash() -> str:
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode()); h.update(f.read())
-    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_RL_SPLIT", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
+    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
         h.update((k + "=" + os.environ.get(k, "")).encode())
     return h.hexdigest()[:16]
 
@@ -61,8 +61,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags += os.environ.get("NMPC_EXTRA_DEFS", "").split()      # development: extra -D switches of experiments (A/B)
     if os.environ.get("NMPC_POISON"):          # debug: uninitialised-read hunt, e.g. NMPC_POISON='__builtin_nan("")' or 1e30
         flags.append("-DNMPC_POISON=" + os.environ["NMPC_POISON"])
-    if os.environ.get("NMPC_RL_SPLIT"):       # development: e.g. NMPC_RL_SPLIT="(NU_)" or "((NU_)+9)"
-        flags.append("-DNMPC_RL_SPLIT(NU_,NZ_)=" + os.environ["NMPC_RL_SPLIT"])
     if os.environ.get("NMPC_SHIFT_ESCALATION"):       # development (A/B)
         flags.append("-DNMPC_SHIFT_ESCALATION=" + os.environ["NMPC_SHIFT_ESCALATION"])
     only = os.environ.get("NMPC_COL_ONLY_M")   # development: instantiate the column kernel for one team size only (fast rebuilds)

@@ -727,18 +727,22 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
 
         // ============ C. forward sweep: du_k = -(t + Uuu' du), t = rhs' + Uux' dx_k with the pivot rows as stored (times -1/pivot),
         // then dx_{k+1} = A dx_k + B du_k - c_k per robot.
-        // Teams with NU <= 16: no LDS staging and no scalar round trips.  Three lane roles, one register each:
+        // No LDS staging and no scalar round trips.  Three lane roles, one register each:
         //   S (lane r < NX)        holds dx[r]; updates its own state with its robot's (a, b, c) coefficients
-        //   T (lane 16 + j)        holds the state part and the right-hand side of pivot row j: t_j = sum_c bcast(dx_c) * row[c],
+        //   T (lane TB + j)        holds the state part and the right-hand side of pivot row j: t_j = sum_c bcast(dx_c) * row[c],
         //                          NX multiply-adds whose DPP operand is dx (its rows of 16 lanes replicated by v_permlane16_swap)
-        //   B (lane 48 + j)        holds the control part of pivot row j (zero up to the diagonal): back substitution, step c
+        //   B (lane TB + 32 + j)   holds the control part of pivot row j (zero up to the diagonal): back substitution, step c
         //                          adds bcast(du_c) * row[c] to every later row's accumulator — one multiply-add per control
+        //                          (controls 16.. of the larger teams sit in the second row of 16 B lanes: v_readlane broadcast)
         // Each T / B lane loads ITS row straight from HBM/L2 into registers (dwordx4, PD stages ahead).
-        if constexpr (NU <= 16 && NX <= 32) {
+        if constexpr (NU <= 32 && NX <= 32) {
             constexpr int LDC = G::LDC, CT = (NX + 3) & ~1, CH = CT / 2, PD = 2;
             static_assert(NU + CT <= LDC && NU <= CT, "row chunks of the forward sweep");
-            const bool isT = tid >= 16 && tid < 16 + NU, isB = tid >= 48 && tid < 48 + NU;
-            const double2 *rowp = reinterpret_cast<const double2 *>(gkt + (isT ? (tid - 16) * LDC + NU : (isB ? (tid - 48) * LDC : NU)));
+            // first T lane / first B lane (32 apart: v_permlane32_swap carries t across).  Up to 16 controls both roles fit one row of
+            // 16 lanes each; measured, rows 1 and 3 (lanes 16.., 48..) are 2.5 % faster for six robots than rows 0 and 2
+            constexpr int TB = (NU <= 16) ? 16 : 0, BB = TB + 32;
+            const bool isT = tid >= TB && tid < TB + NU, isB = tid >= BB && tid < BB + NU;
+            const double2 *rowp = reinterpret_cast<const double2 *>(gkt + (isT ? (tid - TB) * LDC + NU : (isB ? (tid - BB) * LDC : NU)));
             double kq[PD][CT];
             auto fetch = [&](auto dc, int k) {
                 constexpr int d = decltype(dc)::value;
@@ -761,13 +765,13 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                         int ln = tid;
                         asm volatile("" : "+v"(ln));
                         const int fr = ln < NX ? ln : 0, fi = fr / 3, fd = fr - 3 * fi;
-                        const int srcT = 4 * (3 * fi + 2), srcU = 4 * (48 + (fd < 2 ? 2 * fi : 2 * fi + 1));
+                        const int srcT = 4 * (3 * fi + 2), srcU = 4 * (BB + (fd < 2 ? 2 * fi : 2 * fi + 1));
                         // coefficients of my state's row of [A B | c] (independent of the recursion: issued first)
                         const double sn = SN[k * M_ + fi], cs = CS[k * M_ + fi], uv = U[k * NU + 2 * fi], uw = U[k * NU + 2 * fi + 1];
                         const double xk = X[k * NX + fr], xn = X[(k + 1) * NX + fr];
                         const double dxt = lane_gather(srcT, dx);
                         double u0 = dx, u1 = dx;
-                        swap16(u0, u1);                   // u0 = lanes 0..15 of dx in both rows of each half, u1 = lanes 16..31 (the T lanes sit in row 1)
+                        swap16(u0, u1);                   // u0 = lanes 0..15 of dx in both rows of each half, u1 = lanes 16..31
                         asm("s_nop 4" : "+v"(u0));
                         if constexpr (NX > 16) asm("s_nop 0" : "+v"(u1));
                         double t = kq[d][NX];
@@ -777,14 +781,18 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                             else fmac_rowb<(c & 15)>(t, u1, kq[d][c]);
                         });
                         double tb = t, tl = t;
-                        swap32(tb, tl);                   // lanes 48 + j <- t of lanes 16 + j
+                        swap32(tb, tl);                   // lanes BB + j <- t of lanes TB + j
                         static_for<1, NU>([&](auto cc) {
-                            constexpr int c = NU - decltype(cc)::value;      // NU-1 .. 1: du_c is final on lane 48 + c when its turn comes
-                            asm("s_nop 1" : "+v"(tb));
-                            double ub = tb;
-                            fmac_rowb<c>(tb, ub, kq[d][c]);
+                            constexpr int c = NU - decltype(cc)::value;      // NU-1 .. 1: du_c is final on lane BB + c when its turn comes
+                            if constexpr (c < 16) {
+                                asm("s_nop 1" : "+v"(tb));
+                                double ub = tb;
+                                fmac_rowb<c>(tb, ub, kq[d][c]);
+                            } else {
+                                tb = fma(kq[d][c], lane_read(tb, BB + c), tb);
+                            }
                         });
-                        if (ln >= 48 && ln < 48 + NU) DU[k * NU + (ln - 48)] = tb;
+                        if (ln >= BB && ln < BB + NU) DU[k * NU + (ln - BB)] = tb;
                         const double du = lane_gather(srcU, tb);
                         if (k + PD < N) fetch(dc, k + PD);
                         // dx+ = dx + a dx_theta + b du - c:  x: a = -T v sin, b = T cos;  y: a = T v cos, b = T sin;  theta: a = 0, b = T

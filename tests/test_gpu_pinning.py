@@ -260,7 +260,7 @@ def test_kernel_selection_by_team_size_and_batch(built):
             if old is not None:
                 os.environ["NMPC_KERNEL"] = old
     assert choice(R.cfg_two(20), [1, 512, 4096]) == [3, 3, 3]
-    assert choice(R.cfg_six(20), [1, 2048, 2049, 4096]) == [2, 2, 3, 3]
+    assert choice(R.cfg_six(20), [1, 512, 513, 4096]) == [2, 2, 3, 3]
     assert choice(R.cfg_ten(20), [512, 1024, 1025, 4096]) == [2, 2, 3, 3]
     assert choice(R.cfg_six(20), [1, 4096], kernel="3") == [3, 3] and choice(R.cfg_six(20), [1, 4096], kernel="2") == [2, 2]
     # the column kernel keeps only what the sweeps touch in LDS: six robots fit up to ~190 stages (element-per-lane kernel: 88)
