@@ -63,7 +63,11 @@ __device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>
 // update) spread stages / variables over the 64 lanes (coalesced accesses of the instance's contiguous workspace, wave
 // reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
 // recursion) run uniformly on all lanes, lane 0 storing.
-__global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
+#define N_LDS_STAGES(N_) ((N_) + 1)
+#ifndef NMPC_LIDAR_WAVES
+#define NMPC_LIDAR_WAVES 2      // resident waves per SIMD the register budget is set for (measured: 1 -> 27.5 k, 2 -> 29.2 k, 3 -> 21.7 k, 4 -> 19.2 k solves/s)
+#endif
+__global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                           double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
                                                           int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
 {
@@ -72,6 +76,13 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
     const int N = P.N, Nc = P.Nc, R = P.R, ns = P.ns;
     const double T = P.T;
     double *wsb = ws + (size_t)b * (size_t)P.total;
+    // LDS: what the three serial recursions over the horizon read per stage.  They run uniformly on all lanes and every stage
+    // depends on the one before: an L2/HBM round trip per stage (~1 us) is their whole cost when the operands come from the
+    // workspace, so a stage-parallel pass copies them here first and the recursions touch global memory only to store.
+    extern __shared__ double lsm[];
+    double *SB = lsm;                              // [N+1][13]  Hxx(4) gx(3) hvt sin cos pose(3)
+    double *SC = SB + (size_t)(N_LDS_STAGES(P.N)) * 13;      // [Nc][16]   u(2) huu(2) gu(2) K(6) kff(2) du(2)
+    double *SD = SC + (size_t)P.Nc * 16;           // [N+1][3]   pose step
     const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
     double *wo = w_out + (size_t)b * P.nvar;
     const double *lbv = P.lb, *ubv = P.ub, *lbu = P.lb + (size_t)(N + 1) * ns, *ubu = P.ub + (size_t)(N + 1) * ns;
@@ -270,6 +281,19 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 W_(P.ogu, o) = cnt * 2 * P.r[e] * u - (vl - vu);
             }
             __syncthreads();
+            for (int k = lane; k <= N; k += 64) {
+                double *sb = SB + k * 13;
+                sb[0] = W_(P.oHxx, 4 * k); sb[1] = W_(P.oHxx, 4 * k + 1); sb[2] = W_(P.oHxx, 4 * k + 2); sb[3] = W_(P.oHxx, 4 * k + 3);
+                sb[4] = W_(P.ogx, 3 * k); sb[5] = W_(P.ogx, 3 * k + 1); sb[6] = W_(P.ogx, 3 * k + 2);
+                sb[7] = (k < N) ? W_(P.ohvt, k) : 0.0; sb[8] = (k < N) ? W_(P.osn, k) : 0.0; sb[9] = (k < N) ? W_(P.ocs, k) : 0.0;
+                sb[10] = W_(oV, k * ns); sb[11] = W_(oV, k * ns + 1); sb[12] = W_(oV, k * ns + 2);
+            }
+            for (int j = lane; j < Nc; j += 64) {
+                double *sc = SC + j * 16;
+                sc[0] = W_(oU, 2 * j); sc[1] = W_(oU, 2 * j + 1); sc[2] = W_(P.ohuu, 2 * j); sc[3] = W_(P.ohuu, 2 * j + 1);
+                sc[4] = W_(P.ogu, 2 * j); sc[5] = W_(P.ogu, 2 * j + 1);
+            }
+            __syncthreads();
 
             // ---- B. Riccati sweep on z = (pose (3), held control (2)) with inertia correction; uniform on all lanes, stage in registers
             double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
@@ -282,13 +306,14 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                 for (int z = 0; z < 25; z++) P5[z] = 0.0;
 #pragma unroll
                 for (int z = 0; z < 5; z++) p5[z] = 0.0;
-                P5[0] = W_(P.oHxx, 4 * N); P5[1] = P5[5] = W_(P.oHxx, 4 * N + 1); P5[6] = W_(P.oHxx, 4 * N + 2); P5[12] = W_(P.oHxx, 4 * N + 3);
-                p5[0] = W_(P.ogx, 3 * N); p5[1] = W_(P.ogx, 3 * N + 1); p5[2] = W_(P.ogx, 3 * N + 2);
+                P5[0] = SB[N * 13]; P5[1] = P5[5] = SB[N * 13 + 1]; P5[6] = SB[N * 13 + 2]; P5[12] = SB[N * 13 + 3];
+                p5[0] = SB[N * 13 + 4]; p5[1] = SB[N * 13 + 5]; p5[2] = SB[N * 13 + 6];
                 for (int k = N - 1; k >= 0; k--) {
                     const int j = cof(k);
-                    const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1), s = W_(P.osn, k), c = W_(P.ocs, k), a = -T * u0 * s, bq = T * u0 * c;
-                    const double cd0 = W_(oV, (k + 1) * ns) - (W_(oV, k * ns) + T * u0 * c), cd1 = W_(oV, (k + 1) * ns + 1) - (W_(oV, k * ns + 1) + T * u0 * s),
-                                 cd2 = W_(oV, (k + 1) * ns + 2) - (W_(oV, k * ns + 2) + T * u1);
+                    const double *sb = SB + k * 13, *sc = SC + j * 16;
+                    const double u0 = sc[0], u1 = sc[1], s = sb[8], c = sb[9], a = -T * u0 * s, bq = T * u0 * c;
+                    const double cd0 = sb[13 + 10] - (sb[10] + T * u0 * c), cd1 = sb[13 + 11] - (sb[11] + T * u0 * s),
+                                 cd2 = sb[13 + 12] - (sb[12] + T * u1);
                     // At = [[A, B], [0, I]] acts on columns, then on rows: G = P At, M = At^T G (At is sparse: written out)
                     double pb[5], G5[25], Mx[25], mv[5];
 #pragma unroll
@@ -306,14 +331,14 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                     }
                     mv[0] = pb[0]; mv[1] = pb[1]; mv[2] = a * pb[0] + bq * pb[1] + pb[2]; mv[3] = T * c * pb[0] + T * s * pb[1] + pb[3]; mv[4] = T * pb[2] + pb[4];
                     if (k >= 1) {
-                        const double h1 = W_(P.oHxx, 4 * k + 1);
-                        Mx[0] += W_(P.oHxx, 4 * k); Mx[1] += h1; Mx[5] += h1; Mx[6] += W_(P.oHxx, 4 * k + 2); Mx[12] += W_(P.oHxx, 4 * k + 3);
-                        mv[0] += W_(P.ogx, 3 * k); mv[1] += W_(P.ogx, 3 * k + 1); mv[2] += W_(P.ogx, 3 * k + 2);
+                        const double h1 = sb[1];
+                        Mx[0] += sb[0]; Mx[1] += h1; Mx[5] += h1; Mx[6] += sb[2]; Mx[12] += sb[3];
+                        mv[0] += sb[4]; mv[1] += sb[5]; mv[2] += sb[6];
                     }
-                    { const double hv = W_(P.ohvt, k); Mx[2 * 5 + 3] += hv; Mx[3 * 5 + 2] += hv; }
+                    { const double hv = sb[7]; Mx[2 * 5 + 3] += hv; Mx[3 * 5 + 2] += hv; }
                     if (k <= Nc - 1) {        // the stage where control j is decided carries its whole diagonal / gradient
-                        Mx[18] += W_(P.ohuu, 2 * j) + delta; Mx[24] += W_(P.ohuu, 2 * j + 1) + delta;
-                        mv[3] += W_(P.ogu, 2 * j); mv[4] += W_(P.ogu, 2 * j + 1);
+                        Mx[18] += sc[2] + delta; Mx[24] += sc[3] + delta;
+                        mv[3] += sc[4]; mv[4] += sc[5];
                         const double dv = Mx[18];
                         if (!(uni(dv) > 0.0)) { ok = false; break; }
                         const double l43 = Mx[23] / dv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
@@ -326,9 +351,10 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
                             if (q_ < 3) { Kk[q_] = -y3; Kk[3 + q_] = -y4; } else { kk[0] = -y3; kk[1] = -y4; }
                         }
                         if (lane == 0) {
+                            double *sk = SC + j * 16 + 6;
 #pragma unroll
-                            for (int q_ = 0; q_ < 6; q_++) W_(P.oKg, 6 * j + q_) = Kk[q_];
-                            W_(P.okff, 2 * j) = kk[0]; W_(P.okff, 2 * j + 1) = kk[1];
+                            for (int q_ = 0; q_ < 6; q_++) sk[q_] = Kk[q_];
+                            sk[6] = kk[0]; sk[7] = kk[1];
                         }
                         double Pn[9], pn[3];
 #pragma unroll
@@ -367,30 +393,39 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
             __syncthreads();
 
-            // ---- C. forward sweep: the pose recursion uniform on all lanes, the R distance states of a stage one per lane
+            // ---- C. forward sweep: the pose recursion uniform on all lanes (operands from LDS), then the R distance states of every
+            //      stage in parallel, one (stage, ray) item per lane
             for (int c = lane; c < ns; c += 64) W_(P.odV, c) = 0.0;
             {
                 double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
+                if (lane == 0) { SD[0] = 0.0; SD[1] = 0.0; SD[2] = 0.0; }
                 for (int k = 0; k < N; k++) {
                     const int j = cof(k);
+                    const double *sb = SB + k * 13;
+                    double *sc = SC + j * 16;
                     if (k <= Nc - 1) {
-                        du0 = W_(P.okff, 2 * j) + W_(P.oKg, 6 * j) * dx0 + W_(P.oKg, 6 * j + 1) * dx1 + W_(P.oKg, 6 * j + 2) * dx2;
-                        du1 = W_(P.okff, 2 * j + 1) + W_(P.oKg, 6 * j + 3) * dx0 + W_(P.oKg, 6 * j + 4) * dx1 + W_(P.oKg, 6 * j + 5) * dx2;
-                        if (lane == 0) { W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1; }
+                        du0 = sc[12] + sc[6] * dx0 + sc[7] * dx1 + sc[8] * dx2;
+                        du1 = sc[13] + sc[9] * dx0 + sc[10] * dx1 + sc[11] * dx2;
+                        if (lane == 0) { W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1; sc[14] = du0; sc[15] = du1; }
                     }
-                    const double u0 = W_(oU, 2 * j), u1 = W_(oU, 2 * j + 1), s = W_(P.osn, k), c = W_(P.ocs, k);
-                    const double xn = W_(oV, (k + 1) * ns), yn = W_(oV, (k + 1) * ns + 1), tn = W_(oV, (k + 1) * ns + 2);
-                    const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (xn - (W_(oV, k * ns) + T * u0 * c));
-                    const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (yn - (W_(oV, k * ns + 1) + T * u0 * s));
-                    const double n2 = dx2 + T * du1 - (tn - (W_(oV, k * ns + 2) + T * u1));
+                    const double u0 = sc[0], u1 = sc[1], s = sb[8], c = sb[9];
+                    const double xn = sb[13 + 10], yn = sb[13 + 11], tn = sb[13 + 12];
+                    const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (xn - (sb[10] + T * u0 * c));
+                    const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (yn - (sb[11] + T * u0 * s));
+                    const double n2 = dx2 + T * du1 - (tn - (sb[12] + T * u1));
                     dx0 = n0; dx1 = n1; dx2 = n2;
-                    if (lane == 0) { W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2; }
-                    if (lane < R) {     // dd = G dx + (g - d) at stage k+1
-                        double sx, sy;
-                        const double gg = gdist(lane, xn, yn, sx, sy);
-                        W_(P.odV, (k + 1) * ns + 3 + lane) = sx * n0 + sy * n1 + (gg - W_(oV, (k + 1) * ns + 3 + lane));
+                    if (lane == 0) {
+                        W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2;
+                        SD[3 * (k + 1)] = n0; SD[3 * (k + 1) + 1] = n1; SD[3 * (k + 1) + 2] = n2;
                     }
                 }
+            }
+            __syncthreads();
+            for (int e = lane; e < N * R; e += 64) {      // dd = G dx + (g - d) at stage k1 = 1..N
+                const int k1 = 1 + e / R, m = e - (k1 - 1) * R;
+                double sx, sy;
+                const double gg = gdist(m, SB[k1 * 13 + 10], SB[k1 * 13 + 11], sx, sy);
+                W_(P.odV, k1 * ns + 3 + m) = sx * SD[3 * k1] + sy * SD[3 * k1 + 1] + (gg - W_(oV, k1 * ns + 3 + m));
             }
             __syncthreads();
             // ---- multipliers of the QP: lambda+ by the adjoint recursion (uniform), eta+ from the distance rows (one per lane)
@@ -398,14 +433,15 @@ __global__ __launch_bounds__(64) void lidar_solve_kernel(const LParams P, int B,
             {
                 double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
                 for (int k = N; k >= 1; k--) {
-                    const double dx0 = W_(P.odV, k * ns), dx1 = W_(P.odV, k * ns + 1), dx2 = W_(P.odV, k * ns + 2);
-                    const double H0 = W_(P.oHxx, 4 * k), H1 = W_(P.oHxx, 4 * k + 1), H2 = W_(P.oHxx, 4 * k + 2), H3 = W_(P.oHxx, 4 * k + 3);
-                    double l0 = -(W_(P.ogx, 3 * k) + H0 * dx0 + H1 * dx1), l1 = -(W_(P.ogx, 3 * k + 1) + H1 * dx0 + H2 * dx1), l2 = -(W_(P.ogx, 3 * k + 2) + H3 * dx2);
+                    const double *sb = SB + k * 13;
+                    const double dx0 = SD[3 * k], dx1 = SD[3 * k + 1], dx2 = SD[3 * k + 2];
+                    const double H0 = sb[0], H1 = sb[1], H2 = sb[2], H3 = sb[3];
+                    double l0 = -(sb[4] + H0 * dx0 + H1 * dx1), l1 = -(sb[5] + H1 * dx0 + H2 * dx1), l2 = -(sb[6] + H3 * dx2);
                     if (k < N) {
-                        const int j = cof(k);
-                        const double u0 = W_(oU, 2 * j);
+                        const double *sc = SC + cof(k) * 16;
+                        const double u0 = sc[0];
                         l0 += ln0; l1 += ln1;
-                        l2 += ln2 + (-T * u0 * W_(P.osn, k)) * ln0 + (T * u0 * W_(P.ocs, k)) * ln1 - W_(P.ohvt, k) * W_(P.odU, 2 * j);
+                        l2 += ln2 + (-T * u0 * sb[8]) * ln0 + (T * u0 * sb[9]) * ln1 - sb[7] * sc[14];
                     }
                     ln0 = l0; ln1 = l1; ln2 = l2;
                     if (lane == 0) { W_(P.olamn, 3 * k) = l0; W_(P.olamn, 3 * k + 1) = l1; W_(P.olamn, 3 * k + 2) = l2; }
@@ -580,6 +616,7 @@ struct nmpc_lidar_handle {
     nmpc_lidar_config_t cfg;
     nmpc_lidar::LParams P;
     int32_t max_batch;
+    size_t lds_bytes;           // dynamic LDS of the solve kernel: per-stage operands of the three recursions
     int device;
     double *ws, *lb, *ub;
     int64_t ws_bytes;
@@ -606,6 +643,10 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     if (!h) return NMPC_E_NOMEM;
     if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
     h->cfg = *cfg; h->max_batch = max_batch;
+    h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3);
+    if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU (N ~ 1000 with Nc = N / 2)
+    if (h->lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)nmpc_lidar::lidar_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) { free(h); return NMPC_E_HIP; }
     nmpc_lidar::LParams &P = h->P;
     memset(&P, 0, sizeof(P));
     P.N = N; P.Nc = Nc; P.R = R; P.ns = ns; P.max_iter = cfg->max_iter; P.nvar = nv; P.ng = nmpc_lidar_n_g(cfg); P.np = nmpc_lidar_n_p(cfg);
@@ -663,7 +704,7 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
+    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)B), dim3(64), h->lds_bytes, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
