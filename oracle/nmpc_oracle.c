@@ -73,6 +73,9 @@ typedef struct {
     int max_iter;
     /* iterate + step */
     double *X, *U, *lam, *S, *Z, *dX, *dU, *lamn, *dS, *dZ;
+    double *dXc, *dUc, *dSc, *dZc, *lamnc;   /* EXPERIMENT (NMPC_ORACLE_PC=3): the corrected step next to the plain one */
+    double *corr;      /* EXPERIMENT (NMPC_ORACLE_PC): second-order complementarity term ds dz / s of a predictor step, per slot */
+    int pc;            /* 0 off; 1: corrector with the barrier parameter unchanged; 2: Mehrotra (affine predictor, mu scaled by (mu_aff/mu_cur)^3) */
     double *Xt, *Ut, *St;
     double *sn, *cs, *C, *H, *Ht, *Ct, *snt, *cst;
     double *Hxx, *gx, *huu, *gu, *hvt, *Kg, *kff;
@@ -106,6 +109,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     w->thb = isfinite(c->th_max) ? 1 : 0;
     w->trace = getenv("NMPC_ORACLE_TRACE") != NULL;
     w->max_restarts = getenv("NMPC_ORACLE_MAX_RESTARTS") ? atoi(getenv("NMPC_ORACLE_MAX_RESTARTS")) : 3;
+    w->pc = getenv("NMPC_ORACLE_PC") ? atoi(getenv("NMPC_ORACLE_PC")) : 0;
     w->nxb = m * (w->thb ? 3 : 2);
     w->nh = 2 * w->nu + 2 * w->nxb + w->M + m * w->K;
     w->o_ul = 0; w->o_uu = w->nu; w->o_xl = 2 * w->nu; w->o_xu = w->o_xl + w->nxb;
@@ -128,7 +132,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     }
     size_t nX = (size_t)(N + 1) * w->nx, nU = (size_t)N * w->nu, nH = (size_t)(N + 1) * w->nh;
 #define AL(p, n) w->p = (double *)calloc((n), sizeof(double))
-    AL(X, nX); AL(U, nU); AL(lam, nX); AL(S, nH); AL(Z, nH); AL(dX, nX); AL(dU, nU); AL(lamn, nX); AL(dS, nH); AL(dZ, nH);
+    AL(X, nX); AL(U, nU); AL(lam, nX); AL(S, nH); AL(Z, nH); AL(dX, nX); AL(dU, nU); AL(lamn, nX); AL(dS, nH); AL(dZ, nH); AL(corr, nH); AL(dXc, nX); AL(dUc, nU); AL(dSc, nH); AL(dZc, nH); AL(lamnc, nX);
     AL(Xt, nX); AL(Ut, nU); AL(St, nH);
     AL(sn, (size_t)N * m); AL(cs, (size_t)N * m); AL(snt, (size_t)N * m); AL(cst, (size_t)N * m);
     AL(C, nX); AL(Ct, nX); AL(H, nH); AL(Ht, nH);
@@ -142,7 +146,7 @@ static void ws_free(ws_t *w)
 {
     double **ps[] = {&w->X, &w->U, &w->lam, &w->S, &w->Z, &w->dX, &w->dU, &w->lamn, &w->dS, &w->dZ, &w->Xt, &w->Ut, &w->St,
                      &w->sn, &w->cs, &w->snt, &w->cst, &w->C, &w->Ct, &w->H, &w->Ht, &w->Hxx, &w->gx, &w->huu, &w->gu,
-                     &w->hvt, &w->Kg, &w->kff};
+                     &w->hvt, &w->Kg, &w->kff, &w->corr, &w->dXc, &w->dUc, &w->dSc, &w->dZc, &w->lamnc};
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); i++) free(*ps[i]);
     free(w);
 }
@@ -422,6 +426,11 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         }
         double tau = fmax(0.99, 1.0 - mu);
 
+        int pc_pass = 0;
+        double pc_ap = 1.0, pc_ad = 1.0, pc_mm = 0.0;
+        const double mu_keep = mu;
+        if (w->pc == 2) mu = 0.0;          /* EXPERIMENT: Mehrotra's predictor is the affine-scaling step */
+    pc_again:
         /* ---- condensed stage blocks: Hxx, gx (k=1..N), diagonal huu, gu, cross term hvt (k=0..N-1) */
         for (int k = 0; k <= N; k++) {
             const double *x = w->X + (size_t)k * nx, *s_ = w->S + (size_t)k * nh, *z = w->Z + (size_t)k * nh, *h = w->H + (size_t)k * nh;
@@ -433,7 +442,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                     for (int c = 0; c < nx; c++) { Hk[c * nx + c] = 2 * w->qd[c]; g[c] = 2 * w->qd[c] * (x[c] - xs[c]); }
                 /* v = mu/s - sigma (h - s) per slot; g -= Jx^T v; Hxx += Jx^T Sigma Jx - z * hess(h) */
                 double v[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
-                for (int s = 0; s < nh; s++) v[s] = slot_active(w, k, s) ? (mu / s_[s] - z[s] / s_[s] * (h[s] - s_[s])) : 0.0;
+                for (int s = 0; s < nh; s++) v[s] = slot_active(w, k, s) ? (mu / s_[s] - z[s] / s_[s] * (h[s] - s_[s]) - w->corr[(size_t)k * nh + s]) : 0.0;
                 for (int c = 0; c < nx; c++) tmp[c] = 0.0;
                 jxT_apply(w, k, x, v, tmp);
                 for (int c = 0; c < nx; c++) g[c] -= tmp[c];
@@ -472,7 +481,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 for (int c = 0; c < nu; c++) {
                     double sl = s_[w->o_ul + c], su = s_[w->o_uu + c], zl = z[w->o_ul + c], zu = z[w->o_uu + c];
                     w->huu[k * nu + c] = 2 * w->rd[c] + zl / sl + zu / su;
-                    double vl = mu / sl - zl / sl * (h[w->o_ul + c] - sl), vu = mu / su - zu / su * (h[w->o_uu + c] - su);
+                    double vl = mu / sl - zl / sl * (h[w->o_ul + c] - sl) - w->corr[(size_t)k * nh + w->o_ul + c], vu = mu / su - zu / su * (h[w->o_uu + c] - su) - w->corr[(size_t)k * nh + w->o_uu + c];
                     w->gu[k * nu + c] = 2 * w->rd[c] * u[c] - (vl - vu);
                 }
                 for (int i = 0; i < m; i++) {
@@ -625,12 +634,38 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 size_t o = (size_t)k * nh + s;
                 if (!slot_active(w, k, s)) { w->dS[o] = 0.0; w->dZ[o] = 0.0; continue; }
                 double ds = Jd[s] + (w->H[o] - w->S[o]);
-                double dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o];
+                double dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o] - w->corr[o];
                 w->dS[o] = ds; w->dZ[o] = dz;
                 if (s >= w->o_pr) mult_max = fmax(mult_max, fabs(w->Z[o] + dz));
                 if (ds < 0.0) a_p = fmin(a_p, -tau * w->S[o] / ds);
                 if (dz < 0.0) a_d = fmin(a_d, -tau * w->Z[o] / dz);
             }
+        }
+        if (w->pc && pc_pass == 0) {       /* EXPERIMENT: corrector pass with the complementarity product of the predictor */
+            double a_aff = fmin(a_p, a_d), num = 0.0, den = 0.0; int cnt = 0;
+            for (int k = 0; k <= N; k++)
+                for (int s = 0; s < nh; s++) {
+                    size_t o = (size_t)k * nh + s;
+                    if (!slot_active(w, k, s)) { w->corr[o] = 0.0; continue; }
+                    w->corr[o] = w->dS[o] * w->dZ[o] / w->S[o];
+                    num += (w->S[o] + a_aff * w->dS[o]) * (w->Z[o] + a_aff * w->dZ[o]); den += w->S[o] * w->Z[o]; cnt++;
+                }
+            if (w->pc == 2) { double r = (cnt && den > 0.0) ? num / den : 1.0; mu = fmax(w->tol / 10.0, fmin(mu_keep, r * r * r * den / cnt)); }
+            if (w->pc == 3) {   /* keep the plain step */
+                memcpy(w->dXc, w->dX, sizeof(double) * (size_t)(N + 1) * nx); memcpy(w->dUc, w->dU, sizeof(double) * (size_t)N * nu);
+                memcpy(w->dSc, w->dS, sizeof(double) * (size_t)(N + 1) * nh); memcpy(w->dZc, w->dZ, sizeof(double) * (size_t)(N + 1) * nh);
+                memcpy(w->lamnc, w->lamn, sizeof(double) * (size_t)(N + 1) * nx);
+                pc_ap = a_p; pc_ad = a_d; pc_mm = mult_max;
+            }
+            pc_pass = 1;
+            goto pc_again;
+        }
+        if (w->pc) memset(w->corr, 0, sizeof(double) * (size_t)(N + 1) * nh);
+        if (w->pc == 3) {       /* plain step back into place (the merit model below is the plain step's), corrected step aside */
+            double *t, ts;
+            t = w->dX; w->dX = w->dXc; w->dXc = t; t = w->dU; w->dU = w->dUc; w->dUc = t; t = w->dS; w->dS = w->dSc; w->dSc = t;
+            t = w->dZ; w->dZ = w->dZc; w->dZc = t; t = w->lamn; w->lamn = w->lamnc; w->lamnc = t;
+            ts = a_p; a_p = pc_ap; pc_ap = ts; ts = a_d; a_d = pc_ad; pc_ad = ts; ts = mult_max; mult_max = pc_mm; pc_mm = ts;
         }
         /* ---- l1 merit backtracking */
         double th0, phi0 = barrier_and_infeas(w, f, w->C, w->H, w->S, mu, &th0);
@@ -658,7 +693,21 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         if (mcount > 1) mref = fmax(mref, mh1);
         if (mcount > 2) mref = fmax(mref, mh2);
         mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
-        for (int ls = 0; ls < 30; ls++) {
+        int pc_taken = 0;
+        if (w->pc == 3) {       /* the corrected step is taken only at its full fraction-to-boundary length and only if it meets the plain step's Armijo bound */
+            const double ac = pc_ap;
+            for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + ac * w->dXc[i];
+            for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + ac * w->dUc[i];
+            for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + ac * w->dSc[i];
+            ft = eval_point(w, xs, w->Xt, w->Ut, w->snt, w->cst, w->Ct, w->Ht);
+            double tht, phit = barrier_and_infeas(w, ft, w->Ct, w->Ht, w->St, mu, &tht);
+            if (phit + nu_pen * tht <= mref + 1e-4 * ac * D + 1e-13 * fabs(phi0)) {
+                double *t;
+                pc_taken = 1; alpha = ac; a_d = pc_ad;
+                t = w->dZ; w->dZ = w->dZc; w->dZc = t; t = w->lamn; w->lamn = w->lamnc; w->lamnc = t;
+            }
+        }
+        for (int ls = 0; ls < 30 && !pc_taken; ls++) {
             for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
             for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
             for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + alpha * w->dS[i];
