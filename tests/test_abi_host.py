@@ -234,3 +234,34 @@ def test_script_presets_hold_the_scripts_literals(built):
     assert nmpc_amd.script_preset("second_scenario_obstacles").obstacles[1] == (-0.75, 0.0, 0.125)
     with pytest.raises(KeyError):
         nmpc_amd.script_preset("no_such_script")
+
+
+def test_hot_loops_of_the_column_kernel_hold_no_spills(built, tmp_path):
+    """Build check (hipcc cross-compiles here): the two hot loops of the throughput kernel — the backward Riccati stage and the
+    forward sweep, the loops that contain the DPP multiply-adds — hold no scratch (spill) instruction.  A spill reload inside
+    a loop that prefetches waits (vmcnt is in order) for every prefetch in flight; the property is fragile under edits anywhere
+    in the kernel, so it is pinned here for the headline team size."""
+    import importlib
+    import shutil
+    bld = importlib.import_module("nmpc_amd.build")
+    hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")) if c and os.path.exists(c)), None)
+    if hipcc is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(bld.CSRC, "nmpc_solve_col.hip")
+    obj = str(tmp_path / "col.o")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="t"', "-DNMPC_COL_ONLY_M=6",
+                           "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj, "--save-temps=obj"], cwd=bld.CSRC)
+    asm = str(tmp_path / "nmpc_solve_col-hip-amdgcn-amd-amdhsa-gfx950.s")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "asm_loops.py"), asm, "_ZN4nmpc16solve_col_kernelILi6ELi0", "--all"], text=True)
+    loops = []
+    for line in out.splitlines():
+        m = re.search(r"loop\s+(\d+)-\s*(\d+):\s+(\d+) instr, dpp\s+(\d+), .*scratch ld\s+(\d+) st\s+(\d+), vmcnt\(0\)\s+(\d+)", line)
+        if m:
+            loops.append(tuple(int(g) for g in m.groups()))
+    # innermost loop that holds all 282 elimination multiply-adds of a stage, and the forward loop (the 29 of one stage, unrolled twice or not)
+    back = min((l for l in loops if l[3] == 282), key=lambda l: l[2])
+    fwd = min((l for l in loops if l[3] in (29, 58)), key=lambda l: l[2])
+    print("backward stage loop", back, "forward loop", fwd)
+    assert back[4] == 0 and back[5] == 0, out
+    assert fwd[4] == 0 and fwd[5] == 0, out
+    assert back[6] <= 2 and back[2] < 1400, back          # one wait for the pack per stage; ~1200 instructions

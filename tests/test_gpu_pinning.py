@@ -286,3 +286,20 @@ def test_long_horizon_on_the_column_kernel(built):
     ref = O.solve_batch(O.make_config(ocfg, max_iter=1500), P, W0)
     assert (r["status"] == ref["status"]).all() and (r["status"] == 0).all(), (r["status"], ref["status"], r["iters"])
     assert np.max(np.abs(r["x"] - ref["x"]), axis=1).max() <= 1e-6 or (np.max(np.abs(r["x"] - ref["x"]), axis=1) <= 1e-6).mean() >= 0.66
+
+
+def test_cross_lane_instruction_semantics_on_device(built, tmp_path):
+    """The column kernel leans on two gfx950 cross-lane forms whose lane semantics the compiler does not check for inline asm:
+    v_fmac_f64_dpp ... row_newbcast:n (lane n of the executing lane's own row of 16) and v_permlane16_swap / v_permlane32_swap.
+    tools/dpp_probe.hip runs them against a host model (built here with hipcc: the probe is a development tool, not a product file)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")) if c and os.path.exists(c)), None)
+    if hipcc is None:
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "dpp_probe")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tools", "dpp_probe.hip"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(out.stdout)
+    assert out.returncode == 0 and "as expected" in out.stdout, out.stdout + out.stderr
