@@ -34,6 +34,9 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #ifndef NMPC_COL_GB
 #define NMPC_COL_GB 32       // rows per batch of the G = P [B A] gathers (32 = all at once; development knob)
 #endif
+#ifndef NMPC_FW_PD
+#define NMPC_FW_PD 2         // stages the forward sweep requests its rows ahead
+#endif
 #ifndef NMPC_FW_FAKE
 #define NMPC_FW_FAKE 0       // development: 1 = the forward sweep re-reads stage 0's rows (wrong results; separates compute from memory time)
 #endif
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
         //                          (controls 16.. of the larger teams sit in the second row of 16 B lanes: v_readlane broadcast)
         // Each T / B lane loads ITS row straight from HBM/L2 into registers (dwordx4, PD stages ahead).
         if constexpr (NU <= 32 && NX <= 32) {
-            constexpr int LDC = G::LDC, CT = (NX + 3) & ~1, CH = CT / 2, PD = 2;
+            constexpr int LDC = G::LDC, CT = (NX + 3) & ~1, CH = CT / 2, PD = NMPC_FW_PD;
             static_assert(NU + CT <= LDC && NU <= CT, "row chunks of the forward sweep");
             // first T lane / first B lane (32 apart: v_permlane32_swap carries t across).  Up to 16 controls both roles fit one row of
             // 16 lanes each; measured, rows 1 and 3 (lanes 16.., 48..) are 2.5 % faster for six robots than rows 0 and 2
@@ -744,6 +747,10 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
             const bool isT = tid >= TB && tid < TB + NU, isB = tid >= BB && tid < BB + NU;
             const double2 *rowp = reinterpret_cast<const double2 *>(gkt + (isT ? (tid - TB) * LDC + NU : (isB ? (tid - BB) * LDC : NU)));
             double kq[PD][CT];
+#pragma unroll
+            for (int d = 0; d < PD; d++)        // definitely assigned: a ring that is only conditionally loaded counts as live across the whole
+#pragma unroll
+                for (int t = 0; t < CT; t++) kq[d][t] = 0.0;      // interior-point loop (its undefined start value meets the loaded one at every join)
             auto fetch = [&](auto dc, int k) {
                 constexpr int d = decltype(dc)::value;
 #pragma unroll
