@@ -70,7 +70,7 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
 }
 
-template <int M_, int THB>
+template <int M_, int THB, int DL>
 __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                         double *__restrict__ w_out, double *__restrict__ obj_out,
                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     constexpr int RG0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     double *XS = RV + ((N1 * NX > RG0) ? N1 * NX : RG0);   // [NX]
     double *RED = XS + NX;                // [8]
-    double *gd = ws + inst * P.stride2 + P.oDUAL;
+    // slacks and duals of the inequality rows: in the instance's workspace (HBM/L2) for the larger teams, whose LDS budget of
+    // 20 KB (eight instances per CU) they would break; in LDS (DL = 1) for up to four robots when they fit that budget — there the
+    // stage-parallel phases are most of an iteration and their loops make one trip, i.e. one exposed memory latency each
+    double *gd = DL ? (RED + 8) : (ws + inst * P.stride2 + P.oDUAL);
     double *SPp = gd;                     // [N1*NP]   pair slacks
     double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
     double *SO = ZPp + N1 * NP;           // [N1*MK]   obstacle slacks
@@ -1134,24 +1137,28 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
 }
 
 // LDS bytes of one instance of the column-per-lane kernel
-template <int M_, int THB> static size_t col_lds_bytes(const KParams &P)
+template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool duals)
 {
     using G = G2<M_, THB>;
     const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
     size_t d = N1 * G::NX * 3 + N * G::NU * 2 + N * M_ * 2;
-    (void)MK;
     const size_t rg0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     d += (N1 * G::NX > rg0) ? N1 * G::NX : rg0;
     d += G::NX + 8;
+    if (duals) d += 2 * N1 * G::NP + 2 * N1 * MK + 4 * N * G::NU + 2 * N1 * G::NXB;
     return d * sizeof(double);
 }
+// slacks / duals in LDS: up to four robots, when eight instances still share a CU
+template <int M_, int THB> static bool col_duals_in_lds(const KParams &P) { return M_ <= 4 && col_lds_bytes<M_, THB>(P, true) <= 20 * 1024; }
 
 template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
                                                         int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
-    size_t lds = col_lds_bytes<M_, THB>(P);
+    constexpr int DLmax = (M_ <= 4) ? 1 : 0;
+    const bool dl = DLmax && col_duals_in_lds<M_, THB>(P);
+    size_t lds = col_lds_bytes<M_, THB>(P, dl);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = solve_col_kernel<M_, THB>;
+    auto kern = dl ? solve_col_kernel<M_, THB, DLmax> : solve_col_kernel<M_, THB, 0>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1189,7 +1196,7 @@ hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, con
 // LDS bytes one instance of the column-per-lane kernel needs (0 if m is not supported)
 size_t col_kernel_bytes(const KParams &P, int m)
 {
-#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P) : col_lds_bytes<M, 0>(P);
+#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, col_duals_in_lds<M, 1>(P)) : col_lds_bytes<M, 0>(P, col_duals_in_lds<M, 0>(P));
     switch (m) {
         LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(8) LB(10)
     default: return 0;
