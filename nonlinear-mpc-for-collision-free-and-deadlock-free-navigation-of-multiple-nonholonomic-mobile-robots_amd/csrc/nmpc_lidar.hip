@@ -64,6 +64,9 @@ __device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>
 // reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
 // recursion) run uniformly on all lanes, lane 0 storing.
 #define N_LDS_STAGES(N_) ((N_) + 1)
+#ifndef NMPC_LIDAR_UNROLL
+#define NMPC_LIDAR_UNROLL 4      // stages of the forward / adjoint recursions unrolled together: their LDS operand reads issue as one batch
+#endif
 #ifndef NMPC_LIDAR_WAVES
 #define NMPC_LIDAR_WAVES 2      // resident waves per SIMD the register budget is set for (measured: 1 -> 27.5 k, 2 -> 29.2 k, 3 -> 21.7 k, 4 -> 19.2 k solves/s)
 #endif
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             {
                 double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
                 if (lane == 0) { SD[0] = 0.0; SD[1] = 0.0; SD[2] = 0.0; }
+#pragma unroll NMPC_LIDAR_UNROLL
                 for (int k = 0; k < N; k++) {
                     const int j = cof(k);
                     const double *sb = SB + k * 13;
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             double mult_max = 0.0;
             {
                 double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
+#pragma unroll NMPC_LIDAR_UNROLL
                 for (int k = N; k >= 1; k--) {
                     const double *sb = SB + k * 13;
                     const double dx0 = SD[3 * k], dx1 = SD[3 * k + 1], dx2 = SD[3 * k + 2];
