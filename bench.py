@@ -129,13 +129,14 @@ def timed_solves(solver, dP, dW0, steps, warmup, barrier):
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
 
 
-def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version):
+def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id):
     fl_iter = algorithmic_flops_per_iter(ocfg)
     flops_launch = float(sum_iters) * fl_iter
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
-    # the kernel nmpc_solve_batch picks for this team size and batch (nmpc_api.cpp): column-per-lane for throughput batches
-    col = ocfg.m <= 4 or (ocfg.m <= 6 and B > 2048) or (ocfg.m >= 8 and B > 1024)
-    rl = {"bound": "fp64-valu", "kernel": "nmpc::solve_%s_kernel<%d,...>" % ("col" if col else "lds", ocfg.m), "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+    # the kernel nmpc_solve_batch picked for this team size and batch, as the library reports it (nmpc_debug_kernel_choice):
+    # 3 column-per-lane (throughput batches), 2 element-per-lane (latency shapes), 1 HBM-resident fallback
+    kname = {3: "nmpc::solve_col_kernel<%d,...>", 2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % ocfg.m
+    rl = {"bound": "fp64-valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
           "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
           "hbm_frac_of_algorithmic_bytes": algorithmic_bytes_per_solve(ocfg) * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -210,6 +211,7 @@ def main():
     ocfg, B, P, W0 = make_batch(args.workload, rank, args.batch)
     cfg = Hh.to_product_cfg(ocfg, max_iter=args.max_iter)
     solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
+    kernel_id = int(solver.lib.nmpc_debug_kernel_choice(solver._h, B))
     dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
     dt, kern_ms, r = timed_solves(solver, dP, dW0, args.steps, args.warmup, barrier)
 
@@ -260,7 +262,7 @@ def main():
         "library": lib_version,
         "solve_stats": {"mean_iters": sum_iters / (B * world), "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / (B * world), "max_kkt_converged": float(allst[:, 4].max())},
-        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version),
+        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version, kernel_id),
     }
     if world > 1:
         per_rank_bytes = B * (cfg.n_var * 8 + 8)
@@ -311,7 +313,7 @@ def main():
                                  "m": oc2.m, "N": oc2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
                                  "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
                                  "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
-                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version)})
+                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version, int(s2.lib.nmpc_debug_kernel_choice(s2._h, B2)))})
             del s2
             torch.cuda.empty_cache()
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,

@@ -151,7 +151,7 @@ int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 
 static int kernel_for_batch(const nmpc_handle_t *h, int32_t B)
 {
     int kern = h->kernel;
-    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 1024) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 512))) kern = 2;
+    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 256) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 512))) kern = 2;
     return kern;
 }
 
@@ -170,9 +170,9 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     // Launch shape.  The column-per-lane kernel (one wave per instance, two instances per SIMD up to six robots) is the
     // throughput path.  A batch that cannot fill those slots is a latency problem instead (the launch lasts as long as its longest
     // solve): there the element-per-lane kernel, one instance per SIMD and, for still smaller batches, 2-4 waves per instance, is
-    // faster.  Measured (solves/s, column | element), six robots: B=256 14.2 k | 17.0 k, 512 28.0 k | 30.7 k, 1024 54.0 k | 46.4 k,
-    // 2048 97 k | 89 k, 4096 155 k | 104 k, 8192 195 k | 131 k, 16384 225 k | 145 k; ten robots N=20: B=512 11.7 k | 13.3 k,
-    // 1024 22.4 k | 23.0 k, 2048 41.5 k | 25.5 k, 4096 50 k | 27 k.
+    // faster.  Measured (solves/s, column | element), six robots: B=256 14.7 k | 16.7 k, 512 28.6 k | 31.0 k, 1024 54.0 k | 46.4 k,
+    // 2048 97 k | 89 k, 4096 164 k | 104 k, 8192 205 k | 131 k, 16384 251 k | 145 k; ten robots N=20: B=256 10.4 k | 11.9 k,
+    // 512 13.1 k | 13.4 k, 1024 25.5 k | 23.0 k, 2048 41.5 k | 25.5 k, 4096 59 k | 27 k; N=30: B=256 3.4 k | 3.8 k, 512 5.7 k | 4.7 k.
     const int kern = kernel_for_batch(h, B);
     hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                    : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)

@@ -261,7 +261,7 @@ def test_kernel_selection_by_team_size_and_batch(built):
                 os.environ["NMPC_KERNEL"] = old
     assert choice(R.cfg_two(20), [1, 512, 4096]) == [3, 3, 3]
     assert choice(R.cfg_six(20), [1, 512, 513, 4096]) == [2, 2, 3, 3]
-    assert choice(R.cfg_ten(20), [512, 1024, 1025, 4096]) == [2, 2, 3, 3]
+    assert choice(R.cfg_ten(20), [256, 257, 1024, 4096]) == [2, 3, 3, 3]
     assert choice(R.cfg_six(20), [1, 4096], kernel="3") == [3, 3] and choice(R.cfg_six(20), [1, 4096], kernel="2") == [2, 2]
     # the column kernel keeps only what the sweeps touch in LDS: six robots fit up to ~190 stages (element-per-lane kernel: 88)
     assert choice(R.cfg_six(120), [1, 64], max_batch=64) == [3, 3]
