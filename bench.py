@@ -349,6 +349,18 @@ def main():
                                           "algorithmic_bytes_per_launch": alg_bytes,
                                           "note": "achieved = modelled workspace traffic (30 state-sized array passes per iteration x iterations), not PMC; "
                                                   "the kernel is latency-bound (two serial recursions over 100 stages per iteration), not bandwidth-bound"}})
+        # PMC traffic of the LIDAR kernel (profiles/r2_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
+        try:
+            tjl = json.load(open(os.path.join(ROOT, "profiles", "r2_lidar", "hbm_traffic.json")))
+            rll = out["sweep"][-1]["roofline"]
+            if tjl.get("library_src_hash") and ("src=" + tjl["library_src_hash"]) in lib_version and tjl["workload"].get("batch_per_gpu") == Bl:
+                rll["traffic"] = tjl["hbm_bytes_per_iteration"] * float(itl.sum())
+                rll["traffic_GBps"] = rll["traffic"] / (kl * 1e-3) / 1e9
+                rll["traffic_source"] = "profiles/r2_lidar/hbm_traffic.json@src=%s: PMC bytes per iteration x iterations of this launch" % tjl["library_src_hash"]
+            else:
+                rll["traffic_source"] = "null: profiles/r2_lidar/hbm_traffic.json was taken from another build or batch (src=%s)" % tjl.get("library_src_hash")
+        except (OSError, KeyError, ValueError):
+            pass
         del ls
         torch.cuda.empty_cache()
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)

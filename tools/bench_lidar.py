@@ -21,4 +21,10 @@ for lanes in [64]:
     r = s.solve_batch(Pl, Wl); torch.cuda.synchronize()
     t = time.perf_counter(); r = s.solve_batch(Pl, Wl); torch.cuda.synchronize(); dt = time.perf_counter() - t
     it = r["iters"].cpu().numpy()
-    print(f"B={B}: {dt*1e3:8.1f} ms  {B/dt:9.0f} solves/s  mean iters {it.mean():.1f} max {it.max()} converged {(r['status'].cpu().numpy()==0).mean():.3f}", flush=True)
+    print(f"B={B}: {dt*1e3:8.1f} ms  {B/dt:9.0f} solves/s  mean iters {it.mean():.1f} max {it.max()} converged {(r['status'].cpu().numpy()==0).mean():.3f}", file=sys.stderr, flush=True)
+    import json
+    # one JSON line in the shape tools/summarize_profiles.py reads (tools/collect_profiles.sh <tag> "tools/bench_lidar.py 4096")
+    print(json.dumps({"metric": "LIDAR-state NMPC solves/sec (V4: N=100, Nc=50)", "value": B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3,
+                      "config": {"workload": "lidar_v4: 1 robot, 13 states (pose + 10 ray distances), N=100, Nc=50, cold start", "batch_per_gpu": B},
+                      "library": nmpc_amd._lib.load().nmpc_version().decode(),
+                      "solve_stats": {"mean_iters": float(it.mean()), "max_iters": float(it.max()), "converged_frac": float((r["status"].cpu().numpy() == 0).mean())}}), flush=True)
