@@ -15,7 +15,8 @@
 //   * a pivot step is  m[a] -= M[j][a] * (m[j] / d_j)  for all remaining rows a: the multiplier M[j][a] sits in lane L(a) of
 //     register m[j] (symmetry) and is broadcast by the DPP operand of the multiply-add itself (v_fmac_f64_dpp row_newbcast),
 //     one DP instruction per row — no LDS round trip, no wave synchronisation, no scalar round trip;
-//   * pivot rows and reciprocal pivots stream to HBM/L2 in the layout the forward sweep of nmpc_solve_lds.hip reads.
+//   * pivot rows stream to HBM/L2 already multiplied by -1/pivot (zero up to the diagonal): the forward sweep below loads them
+//     row-per-lane and needs neither a division nor LDS staging.
 // One wavefront per swarm instance for every team size (ten robots: 50 of 64 lanes, 51 rows = 102 VGPRs).
 #include "nmpc_solve_common.h"
 
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     double *CS = SN + N * M_;             // [N*M]
     double *DX = CS + N * M_;             // [N1*NX]   step
     double *DU = DX + N1 * NX;            // [N*NU]
-    double *RV = DU + N * NU;             // one region, three lives: PK [PACK] the staged pack of the backward sweep, FS [KTS] the staged
-    double *FS = RV, *PK = RV;            // stage factor of the forward sweep, RV [N1*NX] the residuals / QP multipliers of the adjoint recursion
+    double *RV = DU + N * NU;             // one region, two lives: PK [PACK] the staged pack of the backward sweep; RV [N1*NX] the residuals /
+    double *FS = RV, *PK = RV;            // QP multipliers of the adjoint recursion (FS [KTS]: staged stage factor, only the > 32-control forward path)
     constexpr int RG0 = G::KTS > G::PACK ? G::KTS : G::PACK;
     double *XS = RV + ((N1 * NX > RG0) ? N1 * NX : RG0);   // [NX]
     double *RED = XS + NX;                // [8]
