@@ -344,13 +344,15 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                         mv[3] += sc[4]; mv[4] += sc[5];
                         const double dv = Mx[18];
                         if (!(uni(dv) > 0.0)) { ok = false; break; }
-                        const double l43 = Mx[23] / dv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
+                        const double rdv = 1.0 / dv;          // two reciprocals per stage instead of nine divisions (the recursion is uniform: every lane pays them)
+                        const double l43 = Mx[23] * rdv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
                         if (!(uni(d1) > 1e-9 * fabs(uni(d1o))) || !(uni(d1) > 0.0)) { ok = false; break; }
+                        const double rd1 = 1.0 / d1;
                         double Kk[6], kk[2];
 #pragma unroll
                         for (int q_ = 0; q_ < 4; q_++) {
                             const double r3 = (q_ < 3) ? Mx[15 + q_] : mv[3], r4 = (q_ < 3) ? Mx[20 + q_] : mv[4];
-                            const double y4 = (r4 - l43 * r3) / d1, y3 = (r3 - Mx[19] * y4) / dv;
+                            const double y4 = (r4 - l43 * r3) * rd1, y3 = (r3 - Mx[19] * y4) * rdv;
                             if (q_ < 3) { Kk[q_] = -y3; Kk[3 + q_] = -y4; } else { kk[0] = -y3; kk[1] = -y4; }
                         }
                         if (lane == 0) {
