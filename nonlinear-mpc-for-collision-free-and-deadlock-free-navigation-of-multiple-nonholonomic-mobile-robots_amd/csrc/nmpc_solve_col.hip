@@ -33,7 +33,7 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 // 4 (two rows) or 12 (four rows) 32-bit VALU moves per pivot step.  NMPC_COL_DPP=0 keeps the readlane form (A/B).
 // tools/dpp_probe.hip checks the lane semantics of both instructions on the device.
 #ifndef NMPC_COL_GB
-#define NMPC_COL_GB 32       // rows per batch of the G = P [B A] gathers (32 = all at once; development knob)
+#define NMPC_COL_GB ((M_ == 6) ? (NX + 2) / 2 : NX + 1)      // rows per batch of the G = P [B A] gathers.  Measured: six robots in two batches +2.7 % (batch of 3 -> 166 k, 5 -> 171 k, 10 -> 172 k, 13 -> 173 k, all 19 rows at once -> 165 k solves/s); two robots +-0, ten robots -2.5 %: one batch there
 #endif
 #ifndef NMPC_FW_PD
 #define NMPC_FW_PD 2         // stages the forward sweep requests its rows ahead
