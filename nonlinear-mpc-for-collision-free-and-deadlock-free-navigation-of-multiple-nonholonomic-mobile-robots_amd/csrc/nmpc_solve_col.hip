@@ -591,9 +591,12 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
             }
             // prefetch pack N-1 into registers
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
+            // whole 64-lane slices where they fit the scratch region (the tail of the last slice reads into the next pack / the terminal
+            // block, in bounds: (N+1) packs are allocated and PKR*64 <= 2*PACK): no exec-masked tail in every stage.  Measured +3.3 %
+            constexpr bool FULL = PKR * TPB <= RG0 && PKR * TPB <= 2 * G::PACK;
             double pkr[PKR];
 #pragma unroll
-            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
             // the last pivot row and the right-hand sides of a stage are stored at the top of the NEXT stage, behind the wait for that
             // stage's pack: vmcnt counts loads and stores in order, so a store issued just before the wait adds its whole
             // acknowledgement latency to it
@@ -603,12 +606,12 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 lds_sync<TPB>();         // every read of the previous stage's pack is done
 #pragma unroll
                 for (int t = 0; t < PKR; t++) {
-                    int e = tid + t * TPB;
-                    if (e < G::PACK) PK[e] = (e >= G::PK_HD && e < G::PK_HD + NU) ? pkr[t] + delta : pkr[t];
+                    const int e = tid + t * TPB;
+                    if (FULL || e < G::PACK) PK[e] = (e >= G::PK_HD && e < G::PK_HD + NU) ? pkr[t] + delta : pkr[t];
                 }
                 if (k > 0) {
 #pragma unroll
-                    for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
+                    for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
                 }
                 lds_sync<TPB>();
                 double *const gkrow = gkt + (size_t)k * G::KTS + (lvalid ? mycol : NZ + 1);
