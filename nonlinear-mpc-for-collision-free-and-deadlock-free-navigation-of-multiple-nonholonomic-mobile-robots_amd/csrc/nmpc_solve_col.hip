@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
 #if NMPC_COL_DPP
                             // the pivot row register, each of its rows of 16 lanes replicated into all rows (ur[r] = row r everywhere)
                             double ur[NR < 3 ? NR : 4];
-                            if constexpr (NR == 1) asm("s_nop 4" : "+v"(m[j]));      // (see below; in place, no copy of the register)
+                            if constexpr (NR == 1) asm("s_nop 1" : "+v"(m[j]));      // (see below; in place, no copy of the register)
                             ur[0] = m[j];
                             if constexpr (NR == 2) { ur[1] = m[j]; swap16(ur[0], ur[1]); }
                             if constexpr (NR >= 3) {
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                                 ur[3] = ur[1]; swap32(ur[1], ur[3]);
                             }
                             // VALU write -> DPP read of the same VGPR needs 2 wait states (no VALU writes EXEC here); hipcc does not look into asm
-                            if constexpr (NR >= 2) { asm("s_nop 4" : "+v"(ur[0])); asm("s_nop 0" : "+v"(ur[1])); }
+                            if constexpr (NR >= 2) { asm("s_nop 1" : "+v"(ur[0])); asm("s_nop 0" : "+v"(ur[1])); }
                             if constexpr (NR >= 3) { asm("s_nop 0" : "+v"(ur[2])); asm("s_nop 0" : "+v"(ur[3])); }
                             auto elim = [&](auto ac) {
                                 constexpr int a = decltype(ac)::value;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                         const double dxt = lane_gather(srcT, dx);
                         double u0 = dx, u1 = dx;
                         swap16(u0, u1);                   // u0 = lanes 0..15 of dx in both rows of each half, u1 = lanes 16..31
-                        asm("s_nop 4" : "+v"(u0));
+                        asm("s_nop 1" : "+v"(u0));
                         if constexpr (NX > 16) asm("s_nop 0" : "+v"(u1));
                         double t = kq[d][NX];
                         static_for<0, NX>([&](auto cc) {
