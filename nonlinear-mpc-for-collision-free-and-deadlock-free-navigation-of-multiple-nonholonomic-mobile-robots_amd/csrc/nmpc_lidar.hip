@@ -64,6 +64,9 @@ __device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>
 // reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
 // recursion) run uniformly on all lanes, lane 0 storing.
 #define N_LDS_STAGES(N_) ((N_) + 1)
+// cold-start retry: the constants of nmpc_device.h (NMPC_COLD_RETRY_ITERS, NMPC_COLD_RETRIES), mirrored by oracle/lidar_oracle.c
+#define LIDAR_COLD_RETRY_ITERS 500
+#define LIDAR_COLD_RETRIES 2
 #ifndef NMPC_LIDAR_UNROLL
 #define NMPC_LIDAR_UNROLL 4      // stages of the forward / adjoint recursions unrolled together: their LDS operand reads issue as one batch
 #endif
@@ -151,12 +154,22 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
 
     double mu = P.mu_init, f = 0.0, th0 = 0.0, e_c = 0.0;
     int it = 0, n_tiny = 0, n_restart = 0, status = NMPC_STATUS_MAX_ITER;
+    // cold-start retry (the restoration of last resort of the main solver, same constants; see oracle/lidar_oracle.c)
+    int n_cold = 0, it_base = 0;
+    bool cold = false;
     bool need_shift = false, restarting = false;
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0, mh1 = 0, mh2 = 0, mh_mu = -1, mh_nu = -1;
     int mcount = 0;
 
+    auto cold_retry = [&]() { cold = true; n_cold++; it_base = it; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
     for (;;) {      // (re)start of the barrier iteration
+        if (cold) {       // the reference's cold start (V4:184-196): X_k = x0 (pose and scan), U = 0
+            for (int e = ns + lane; e < nV; e += 64) W_(oV, e) = W_(oV, e % ns);
+            for (int e = lane; e < 2 * Nc; e += 64) W_(oU, e) = 0.0;
+            cold = false;
+            __syncthreads();
+        }
         for (int e = ns + lane; e < nV; e += 64) {
             const double lo = lbv[e], hi = ubv[e], v = push_in(W_(oV, e), lo, hi);
             W_(oV, e) = v;
@@ -232,9 +245,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             const double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
             const double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c));
             kkt = E0;
-            if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+            if (!(E0 == E0)) { if (n_cold < LIDAR_COLD_RETRIES && it < P.max_iter) { cold_retry(); break; } status = NMPC_STATUS_NUMERIC; break; }
             if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
             if (it >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+            if (n_cold < LIDAR_COLD_RETRIES && it - it_base >= LIDAR_COLD_RETRY_ITERS) { cold_retry(); break; }
             const double mu_min = P.tol / 10.0;
             for (;;) {
                 const double cm = fmax(fabs(cmax - mu), fabs(cmin - mu));
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                 else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
                 if (delta > 1e20) break;
             }
-            if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+            if (!ok) { if (n_cold < LIDAR_COLD_RETRIES) { cold_retry(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
             if (delta > 0.0) delta_last = delta;
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
             __syncthreads();
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             __syncthreads();
             it++;
             if (n_tiny >= 5) {
-                if (n_restart >= 3) { status = NMPC_STATUS_STALLED; break; }
+                if (n_restart >= 3) { if (n_cold < LIDAR_COLD_RETRIES) { cold_retry(); break; } status = NMPC_STATUS_STALLED; break; }
                 n_restart++; n_tiny = 0; mu = fmax(mu, P.mu_init); restarting = true;
                 break;
             }

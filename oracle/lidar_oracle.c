@@ -31,6 +31,10 @@
 
 #include "../include/nmpc_lidar.h"
 
+/* cold-start retry: the constants of csrc/nmpc_device.h (the LIDAR kernel mirrors this file) */
+#define NMPC_COLD_RETRY_ITERS 500
+#define NMPC_COLD_RETRIES 2
+
 #define RMAX NMPC_LIDAR_MAX_RAYS
 #define NS (3 + RMAX)
 
@@ -153,10 +157,21 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
     n_ineq += 4 * Nc;
     double mu = w->mu_init, f, th0, e_c;
     int it = 0, need_shift = 0, n_tiny = 0, n_restart = 0, restarting = 0;
+    /* Cold-start retry, as in oracle/nmpc_oracle.c: an attempt that stalls after its restarts, fails numerically or runs
+       NMPC_COLD_RETRY_ITERS iterations without converging is restarted from the reference's own cold start (V4:184-196: X_k = x0
+       pose and scan, U = 0), at most twice, the second time with mu = 10 mu_init.  Of 16,384 random V4 instances one crawls for
+       2074 iterations at mu_init = 0.5 and converges in 23-42 from any other initial barrier parameter. */
+    int n_cold = getenv("NMPC_ORACLE_NO_COLD_RETRY") ? NMPC_COLD_RETRIES : 0, it_base = 0, cold = 0;
+#define LIDAR_COLD_RETRY() do { cold = 1; n_cold++; it_base = it; restarting = 1; mu = (n_cold == 1) ? w->mu_init : 10.0 * w->mu_init; n_tiny = 0; n_restart = 0; } while (0)
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0, mh1 = 0, mh2 = 0, mh_mu = -1, mh_nu = -1; int mcount = 0;
 
     for (;;) {      /* (re)start of the barrier iteration */
+        if (cold) {
+            for (int k = 1; k <= N; k++) for (int c = 0; c < ns; c++) w->V[(size_t)k * ns + c] = w->V[c];
+            for (int j = 0; j < 2 * Nc; j++) w->U[j] = 0.0;
+            cold = 0;
+        }
         for (int k = 1; k <= N; k++) for (int c = 0; c < ns; c++) PUSH(w->V[(size_t)k * ns + c], LBV(w, k, c), UBV(w, k, c));
         for (int j = 0; j < Nc; j++) for (int e = 0; e < 2; e++) PUSH(w->U[2 * j + e], LBU(w, j, e), UBU(w, j, e));
         for (int k = 1; k <= N; k++)
@@ -226,9 +241,10 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
             double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
             double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c));
             kkt = E0;
-            if (!(E0 == E0)) { status = NMPC_STATUS_NUMERIC; break; }
+            if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && it < w->max_iter) { LIDAR_COLD_RETRY(); break; } status = NMPC_STATUS_NUMERIC; break; }
             if (E0 <= w->tol) { status = NMPC_STATUS_CONVERGED; break; }
             if (it >= w->max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
+            if (n_cold < NMPC_COLD_RETRIES && it - it_base >= NMPC_COLD_RETRY_ITERS) { LIDAR_COLD_RETRY(); break; }
             const double mu_min = w->tol / 10.0;
             for (;;) {
                 double cm = fmax(fabs(cmax - mu), fabs(cmin - mu));
@@ -345,7 +361,7 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
                 else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
                 if (delta > 1e20) break;
             }
-            if (!ok) { status = NMPC_STATUS_NUMERIC; break; }
+            if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { LIDAR_COLD_RETRY(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
             if (delta > 0.0) delta_last = delta;
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
 
@@ -473,7 +489,7 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
             f = eval_point(w, w->V, w->U, w->sn, w->cs, &th0, &e_c);
             it++;
             if (n_tiny >= 5) {
-                if (n_restart >= w->max_restarts) { status = NMPC_STATUS_STALLED; break; }
+                if (n_restart >= w->max_restarts) { if (n_cold < NMPC_COLD_RETRIES) { LIDAR_COLD_RETRY(); break; } status = NMPC_STATUS_STALLED; break; }
                 n_restart++; n_tiny = 0; mu = fmax(mu, w->mu_init); restarting = 1;
                 break;
             }

@@ -175,3 +175,21 @@ def test_lidar_full_size_batch_matches_oracle(built):
           f"identical iteration counts {(r['iters'] == ref['iters']).mean():.4f}, max iterations {r['iters'].max()}")
     assert (r["status"] == ref["status"]).mean() >= 0.999 and conv.mean() >= 0.99
     assert (dw[conv] <= W_TOL).mean() >= 0.99 and (r["iters"] == ref["iters"])[conv].mean() >= 0.97
+
+
+def test_lidar_cold_start_retry(built):
+    """the crawling instance of tests/golden/lidar_cold_retry_case.npz (2074 iterations at mu_init = 0.5): the kernel's cold-start retry
+    converges it like the oracle's, same point, same iteration count."""
+    import os
+    import torch
+    import nmpc_amd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lidar_cold_retry_case.npz"))
+    cfg = LR.lidar_v4()
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    s = nmpc_amd.LidarSolver(_product(cfg, max_iter=2000), lbx=lbx, ubx=ubx, max_batch=1)
+    r = _np(s.solve_batch(g["p"], g["w0"])); torch.cuda.synchronize()
+    ref = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    print("hip", r["status"], r["iters"], "oracle", ref["status"], ref["iters"])
+    assert r["status"][0] == 0 and ref["status"][0] == 0
+    assert abs(int(r["iters"][0]) - int(ref["iters"][0])) <= 3 and 1000 <= r["iters"][0] <= 1100
+    assert np.max(np.abs(r["x"] - ref["x"])) <= W_TOL

@@ -100,3 +100,20 @@ def test_oracles_are_clean_under_asan_and_ubsan():
     r = subprocess.run(["make", "-C", here, "-B", "asan_check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_cold_start_retry_rescues_the_crawling_instance(monkeypatch):
+    """tests/golden/lidar_cold_retry_case.npz: the one instance of 16,384 seeded V4 instances that needs 2074 iterations at
+    mu_init = 0.5 (and 23-42 from any other initial barrier parameter).  Without the retry: max_iter; with it: the third attempt
+    (cold start, mu = 10 mu_init) converges, 1024 iterations in all."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lidar_cold_retry_case.npz"))
+    cfg = LR.lidar_v4()
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    r = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    assert r["status"][0] == 0 and 1000 <= r["iters"][0] <= 1100, (r["status"], r["iters"])
+    k = LR.kkt_report(cfg, r["x"][0], g["p"][0], tol_active=1e-4)
+    assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, k
+    monkeypatch.setenv("NMPC_ORACLE_NO_COLD_RETRY", "1")
+    r0 = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    assert r0["status"][0] == 1 and r0["iters"][0] == 2000, (r0["status"], r0["iters"])
