@@ -44,9 +44,18 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #ifndef NMPC_COL_DPP
 #define NMPC_COL_DPP 1
 #endif
+#ifndef NMPC_COL_RP
+#define NMPC_COL_RP 1        // row-paired backward sweep for two to six robots (see the sweep); 0 keeps one row per register (A/B)
+#endif
 
 // lane that owns column c of the augmented matrix: state column NU + s on lane s, control column a on lane NX + a
 #define LC(c) (((c) < NU) ? NX + (c) : (c) - NU)
+
+// row-paired layout: register slot / half of control row j (natural order v_0, omega_0, v_1, ...), and whether a control register
+// still holds a row that has not been a pivot after pivot jj
+constexpr int rp_slot(int j) { return 2 * ((j >> 1) >> 1) + (j & 1); }
+constexpr int rp_half(int j) { return (j >> 1) & 1; }
+constexpr bool rp_live(int i, int jj, int nc, int nu) { return i >= nc || (4 * (i >> 1) + (i & 1) > jj) || (4 * (i >> 1) + 2 + (i & 1) > jj && 4 * (i >> 1) + 2 + (i & 1) < nu); }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int N_> __device__ __forceinline__ void fmac_rowb(double &acc, double u, double nr)      // acc += u[lane N_ of my row of 16] * nr
@@ -83,6 +92,9 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
     static_assert(NZ <= 64, "one lane per column of the augmented matrix");
     constexpr int NR = (NZ + 15) / 16;     // rows of 16 lanes that hold columns
+    // row-paired backward sweep (two to six robots): MP robots per half, NC control + NS state register slots, slot RR = right-hand side
+    constexpr bool RP = NMPC_COL_RP && M_ >= 2 && M_ <= 6;
+    constexpr int MP = (M_ + 1) / 2, NC = 2 * MP, NS = 3 * MP, RR = NC + NS;
     const int tid = threadIdx.x;
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
@@ -560,6 +572,178 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
         bool ok;
         for (;;) {
             ok = true;
+            if constexpr (RP) {
+            // ==== row-paired sweep (up to six robots): BOTH 32-lane halves of the wave hold every column, and the rows are split between
+            // them by robot parity — the lower half keeps the rows of robots 0, 2, 4 (and the right-hand side), the upper half those of
+            // robots 1, 3, 5.  Register m[i] therefore carries TWO rows, (half 0, slot i) and (half 1, slot i); slots: 2p + d = control d of
+            // the half's p-th robot, NC + 3p + d = its state d, RR = right-hand side.  The columns mirror that inside each half: wave-row
+            // (16 lanes) w holds the columns of the robots of parity w, at position = slot.  A pivot step needs, on the lanes of half h, the
+            // multipliers M[j][col(h, slot)]: position `slot` of wave-row h of the pivot row — so with ur = [P0 P0 P1 P1] (Pw = wave-row w of
+            // the pivot row's half, v_permlane16/32_swap) ONE v_fmac_f64_dpp row_newbcast:slot eliminates the two rows of a register:
+            // 159 instead of 282 DP instructions for six robots, 16 instead of 31 matrix registers, and half as many rows in the
+            // gathers of P [B A], the row operations of [B A]^T G and the Hessian additions.  Pivot order, the stored pivot rows and the
+            // cost-to-go left for the next stage are those of the single-row layout.
+            const int rh = tid >> 5, rw = (tid >> 4) & 1, rn = tid & 15;
+            const bool cc_ = rn < NC;                                          // my column is a control
+            const int cp = cc_ ? (rn >> 1) : (rn - NC) / 3, cd = cc_ ? (rn & 1) : (rn - NC) - 3 * cp, crob = 2 * cp + rw;
+            const bool cvalid = rn < RR && crob < M_, c_state = cvalid && !cc_, c_ctrl = cvalid && cc_;
+            const int rcol = cvalid ? (cc_ ? 2 * crob + cd : NU + 3 * crob + cd) : 0;      // natural column index
+            auto rob_ok = [&](int p) { return (M_ % 2 == 0) || p < MP - 1 || rh == 0; };  // the upper half's last robot slot is empty for odd teams
+            int hoff[RR];
+            static_for<0, RR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr bool au = i < NC;
+                constexpr int p = au ? (i >> 1) : (i - NC) / 3, d = au ? (i & 1) : (i - NC) - 3 * p;
+                const int rob = 2 * p + rh;                                    // robot of my half's row in this register
+                const int a = au ? 2 * rob + d : NU + 3 * rob + d;             // its natural row index
+                int h = G::PK_ZERO;
+                if constexpr (!au && d < 2) {        // x / y row: pair blocks (negated in the pack) and the xy term of the own robot
+                    const int lo = rob < crob ? rob : crob, hi = rob < crob ? crob : rob;
+                    const int pe = G::PK_E + 3 * (lo * (2 * M_ - lo - 1) / 2 + (hi - lo - 1)) + d + cd;
+                    h = (c_state && cd < 2) ? ((rob == crob) ? G::PK_HXY + rob : pe) : h;
+                }
+                if constexpr (au && d == 0) h = (c_state && cd == 2 && crob == rob) ? G::PK_HVT + rob : h;       // (v_i, theta_i)
+                if constexpr (!au && d == 2) h = (c_ctrl && cd == 0 && crob == rob) ? G::PK_HVT + rob : h;       // (theta_i, v_i)
+                h = (rcol == a) ? G::PK_HD + a : h;
+                hoff[i] = 8 * ((cvalid && rob < M_) ? h : G::PK_ZERO);
+            });
+            const int goff = 8 * (cvalid ? G::PK_G + rcol : G::PK_ZERO), cfo = 8 * (G::PK_CF + 3 * rcol);
+            const int cbo = 8 * (G::PK_C + 3 * rh), cf1 = 8 * (G::PK_CF + 6 * rh), cf2 = 8 * (G::PK_CF + 3 * NU + 9 * rh);
+            // gather sources of G = P [B A] inside my wave-row:  theta_i, v_i <- x_i, y_i;  omega_i <- theta_i
+            const int lb = tid & ~15;
+            const bool needxy = (c_state && cd == 2) || (c_ctrl && cd == 0), needth = c_ctrl && cd == 1;
+            const int srcA2 = 4 * (needxy ? lb + NC + 3 * cp : (needth ? lb + NC + 3 * cp + 2 : tid));
+            const int srcB2 = 4 * (needxy ? lb + NC + 3 * cp + 1 : (needth ? lb + NC + 3 * cp + 2 : tid));
+            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N
+            double m[RR + 1];
+            {
+                const double *pkN = gpack + (size_t)N * G::PACK;
+                const double hdN = c_state ? pkN[G::PK_HD + rcol] : 0.0, gN = c_state ? pkN[G::PK_G + rcol] : 0.0;
+                static_for<0, NC>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
+                static_for<NC, RR>([&](auto rc) { constexpr int r = decltype(rc)::value; m[r] = (c_state && rw == rh && rn == r) ? hdN : 0.0; });
+                m[RR] = gN;
+            }
+            constexpr int PKR = (G::PACK + TPB - 1) / TPB;
+            constexpr bool FULL = PKR * TPB <= RG0 && PKR * TPB <= 2 * G::PACK;
+            double pkr[PKR];
+#pragma unroll
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            double pend_row = 0.0, pend_rhs = 0.0;
+            for (int k = N - 1; k >= 0; k--) {
+                lds_sync<TPB>();
+#pragma unroll
+                for (int t = 0; t < PKR; t++) {
+                    const int e = tid + t * TPB;
+                    if (FULL || e < G::PACK) PK[e] = (e >= G::PK_HD && e < G::PK_HD + NU) ? pkr[t] + delta : pkr[t];
+                }
+                if (k > 0) {
+#pragma unroll
+                    for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(k - 1) * G::PACK + e] : 0.0; }
+                }
+                lds_sync<TPB>();
+                // the lower half stores the pivot rows; every other lane shares the padding slot of the row
+                double *const gkrow = gkt + (size_t)k * G::KTS + ((cvalid && rh == 0) ? rcol : NZ + 1);
+                if (k < N - 1) {
+                    gkrow[G::KTS + (NU - 1) * G::LDC] = pend_row;
+                    if (tid < NU) gkt[(size_t)(k + 1) * G::KTS + tid * G::LDC + NZ] = pend_rhs;
+                }
+                double kO, kA, kB;
+                {
+                    const double c0 = lds_ld(PK, cfo, 0), c1 = lds_ld(PK, cfo, 8), c2 = lds_ld(PK, cfo, 16);
+                    kO = c_state ? c0 : 0.0; kA = c_state ? c1 : (c_ctrl ? c0 : 0.0); kB = c_state ? c2 : (c_ctrl ? c1 : 0.0);
+                }
+                // ---- 1. right-hand side p + P b, b = -c_k: each half sums over its own state rows, the halves are then added
+                {
+                    double acc = 0.0;
+                    static_for<0, NS>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value, p = s / 3, d = s - 3 * p;
+                        double cv = lds_ld(PK, cbo, 8 * (6 * p + d));
+                        if constexpr ((M_ & 1) && p == MP - 1) cv = rh ? 0.0 : cv;
+                        acc = fma(m[NC + s], cv, acc);
+                    });
+                    double a2 = acc, b2 = acc;
+                    swap32(a2, b2);                       // a2 = lower half's sum everywhere, b2 = upper half's
+                    m[RR] -= a2 + b2;
+                }
+                // ---- 2. G = P [B A] (and the same combination of the right-hand side): own column + two gathered columns
+                {
+                    double tA[NS + 1], tB[NS + 1];
+                    static_for<0, NS + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q] = lane_gather(srcA2, m[NC + q]); tB[q] = lane_gather(srcB2, m[NC + q]); });
+                    static_for<0, NS + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NC + q] = fma(kB, tB[q], fma(kA, tA[q], kO * m[NC + q])); });
+                }
+                PROF_T(9);
+                // ---- 3. [B A]^T G: row operations inside each half (a robot's rows live in one half), coefficients per half
+                static_for<0, MP>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    double Tc = lds_ld(PK, cf1, 8 * (12 * p)), Ts = lds_ld(PK, cf1, 8 * (12 * p + 1)), Tt = lds_ld(PK, cf1, 8 * (12 * p + 3));
+                    double ai = lds_ld(PK, cf2, 8 * (18 * p + 7)), bi = lds_ld(PK, cf2, 8 * (18 * p + 8));
+                    if constexpr ((M_ & 1) && p == MP - 1) { Tc = rh ? 0.0 : Tc; Ts = rh ? 0.0 : Ts; Tt = rh ? 0.0 : Tt; ai = rh ? 0.0 : ai; bi = rh ? 0.0 : bi; }
+                    const double gx = m[NC + 3 * p], gy = m[NC + 3 * p + 1], gt = m[NC + 3 * p + 2];
+                    m[2 * p] = fma(Ts, gy, Tc * gx);
+                    m[2 * p + 1] = Tt * gt;
+                    m[NC + 3 * p + 2] = fma(bi, gy, fma(ai, gx, gt));
+                });
+                // ---- 4. Hessian additions and gradient
+                static_for<0, RR>([&](auto rc) { constexpr int r = decltype(rc)::value; m[r] += lds_ld(PK, hoff[r], 0); });
+                m[RR] += lds_ld(PK, goff, 0);
+                PROF_T(10);
+                // ---- 5. NU pivot steps in natural control order.  Pivot j is row (half hj, slot ij); its diagonal sits on lane 48 hj + ij,
+                //      the right-hand side of column j on lane 16 hj + ij of the lower half.  The pivot test runs on the lanes
+                //      themselves (thr = 1e-9 |diagonal as assembled| on the lane that holds the diagonal of its column) and the
+                //      reciprocal — or -1 for a rejected pivot — is read from the diagonal's lane; a rejected pivot does not leave the
+                //      stage early (the rest of the stage computes garbage that the retry overwrites): no branch per pivot
+                double thr = 0.0;
+                static_for<0, NC>([&](auto ic) { constexpr int i = decltype(ic)::value; thr = (rh == rw && rn == i) ? m[i] : thr; });
+                thr = 1e-9 * fabs(thr);
+                auto pivot_inv = [&](double d) { return (d > thr && d > 0.0) ? rcp_nr(d) : -1.0; };
+                double inv_cur = lane_read(pivot_inv(m[rp_slot(0)]), 48 * rp_half(0) + rp_slot(0));
+                double rhsv = 0.0;
+                bool okk = true;
+                static_for<0, NU>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, hj = rp_half(j), ij = rp_slot(j);
+                    const double inv = inv_cur;
+                    okk = okk && (inv > 0.0);
+                    const double rhs_j = lane_read(m[RR], 16 * hj + ij);
+                    rhsv = (tid == j) ? -rhs_j * inv : rhsv;
+                    // own = the pivot row on every lane's own column, in both halves.  The swap leaves the OTHER row of the register in
+                    // both halves of m[ij]: the pivot row itself is dead from here on, the other one keeps its place
+                    double own = m[ij];
+                    if constexpr (hj == 0) swap32(own, m[ij]); else swap32(m[ij], own);
+                    const double rjv = own * inv;
+                    double nrjv = -rjv;
+                    {
+                        int mc = rcol;
+                        asm("" : "+v"(mc));
+                        if constexpr (j == NU - 1) pend_row = (mc > j) ? nrjv : 0.0;
+                        else gkrow[j * G::LDC] = (mc > j) ? nrjv : 0.0;
+                    }
+                    // ur = [P0 P0 P1 P1] from own = [P0 P1 P0 P1]
+                    double ur = own, ub = own;
+                    swap16(ur, ub);                   // ur = [P0 P0 P0 P0], ub = [P1 P1 P1 P1]
+                    swap32(ur, ub);                   // ur = [P0 P0 P1 P1]
+                    asm("s_nop 1" : "+v"(ur));        // VALU write -> DPP read of the same VGPR: 2 wait states
+                    auto elim = [&](auto ac) { constexpr int i = decltype(ac)::value; fmac_rowb<i>(m[i], ur, nrjv); };
+                    if constexpr (j + 1 < NU) {       // the next pivot row first: its reciprocal overlaps the other rows
+                        elim(std::integral_constant<int, rp_slot(j + 1)>{});
+                        inv_cur = lane_read(pivot_inv(m[rp_slot(j + 1)]), 48 * rp_half(j + 1) + rp_slot(j + 1));
+                    }
+                    // a control register stays live while one of its two rows has not been a pivot yet
+                    static_for<0, RR>([&](auto ac) {
+                        constexpr int i = decltype(ac)::value;
+                        if constexpr (rp_live(i, j, NC, NU) && !(j + 1 < NU && i == rp_slot(j + 1))) elim(ac);
+                    });
+                    m[RR] = fma(-rhs_j, rjv, m[RR]);
+                });
+                ok = okk;
+                PROF_T(11);
+                if (!ok) break;
+                pend_rhs = rhsv;
+                if (k == 0) {
+                    gkrow[(NU - 1) * G::LDC] = pend_row;
+                    if (tid < NU) gkt[tid * G::LDC + NZ] = pend_rhs;
+                }
+            }
+            } else {
             // ---- per-lane byte offsets (into the staged pack) of the Hessian addition of element (row a, my column); rebuilt
             //      per sweep so that they only occupy registers while a sweep runs
             int hoff[NZ];
@@ -722,6 +906,7 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                     if (tid < NU) gkt[tid * G::LDC + NZ] = pend_rhs;
                 }
                 // what is left in rows NU.. of the state lanes is [P_k | p_k]
+            }
             }
             if (ok) break;
             ntry++;

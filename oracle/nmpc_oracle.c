@@ -716,8 +716,8 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
-        if (w->trace) fprintf(stderr, "it %3d E0 %.2e mu %.1e f %.6f th0 %.2e alpha %.3g a_p %.3g a_d %.3g delta %.2e nu %.3g dphi %.3g\n",
-                              it, kkt, mu, f, th0, alpha, a_p, a_d, delta_last, nu_pen, dphi);
+        if (w->trace) fprintf(stderr, "it %3d E0 %.2e mu %.1e f %.6f th0 %.2e alpha %.3g a_p %.3g a_d %.3g delta %.2e nu %.3g dphi %.3g ntry %d\n",
+                              it, kkt, mu, f, th0, alpha, a_p, a_d, delta_last, nu_pen, dphi, ntry);
         /* the duals never step further than the primal variables actually moved: a dual step taken
            without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks */
         a_d = fmin(a_d, alpha);
