@@ -13,13 +13,19 @@ stage, batch 4096 per GPU (weak scaling: instances are independent, each rank so
 The one collective the path has, the result gather (RCCL all_gather of w_out / status / iters), is timed
 separately after the solve steps and reported under "gather".
 
+--scaling strong [--batch-total T]: ONE global batch of T instances (default: the batch BASELINE.json quotes for the workload — 4096
+for six / ten robots, 8192 for the composite) is split into contiguous shards (nmpc_amd.shard_range), one per rank: what BASELINE
+configs[3] / [4] describe (4096 over 8 GPUs = 512 per GPU, 8192 over 8 = 1024 per GPU).  The driver's default is weak scaling.
+
 Prints ONE JSON line on rank 0 including
   roofline     — the solve kernel against the fp64 vector peak (the kernel issues no MFMA), algorithmic flops of
                  SURVEY.md §8(d): iters * (F_kkt + F_asm) per solve, duration from HIP events on the launch stream;
   cpu_baseline — the C oracle (oracle/nmpc_oracle.c, OpenMP, one instance per thread) timed on this box's host cores on a
                  bounded sample of the same workload ("port");
   sweep        — (N = 1 only) the other north-star shapes, each with its own roofline: m=2 and m=10 at N=20, B=4096; m=10 at
-                 N=30, B=512; the six-robot + eight-obstacle composite.
+                 N=30, B=512 (one GPU's shard of BASELINE configs[3]) and B=4096 (the whole batch on one GPU); the six-robot +
+                 eight-obstacle composite; six robots at B=16384 (the launch outgrows its longest solve); the LIDAR-state NLP with
+                 its own flop roofline and CPU baseline.
 """
 from __future__ import annotations
 
@@ -61,6 +67,12 @@ def workload(name: str):
     return table[name]
 
 
+# global batch of --scaling strong: what BASELINE.json quotes for the workload (configs[1..4])
+STRONG_TOTAL = {"two": 1024, "six": 4096, "ten20": 4096, "ten": 4096, "composite": 8192}
+# committed rocprofv3 summaries (tools/collect_profiles.sh + tools/summarize_profiles.py) per workload: profiles/<dir>/hbm_traffic.json
+PROFILE_DIR = {"six": "current", "two": "current_two", "ten20": "current_ten20", "ten": "current_ten", "composite": "current_composite", "lidar": "current_lidar"}
+
+
 def algorithmic_flops_per_iter(cfg) -> float:
     """F_kkt + F_asm per interior-point iteration (dense Riccati count)."""
     nx, nu, N, m, M, K = cfg.nx, cfg.nu, cfg.N, cfg.m, cfg.M, cfg.K
@@ -90,7 +102,9 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def make_batch(name, rank, batch=0):
+def make_batch(name, rank, batch=0, shard=None):
+    """shard = (lo, hi): the instances [lo, hi) of ONE global batch of `batch` instances drawn from the rank-0 stream (strong scaling);
+    otherwise every rank draws its own `batch` instances (weak scaling)."""
     import nmpc_amd
     from tests import helpers as Hh
     from oracle import nlp_ref as R
@@ -98,7 +112,7 @@ def make_batch(name, rank, batch=0):
     if batch:
         B = batch
     # synthetic instances of SURVEY.md §8(d); each rank draws its own shard (seed + rank stream)
-    rng = np.random.Generator(np.random.PCG64([Hh.SEED0 + cidx, rank]))
+    rng = np.random.Generator(np.random.PCG64([Hh.SEED0 + cidx, 0 if shard else rank]))
     P = np.stack([Hh.instance(rng, ocfg) for _ in range(B)])
     # instance 0 of every batch is the reference's literal start/goal set (C6:364-388, C2:213-224); the literal
     # x0 of the ten-robot script has coincident robots (status 3 by construction), so that workload keeps its drawn instance
@@ -106,6 +120,9 @@ def make_batch(name, rank, batch=0):
     if lit is not None:
         P[0] = np.concatenate(lit)
     W0 = np.stack([R.cold_start(ocfg, p[: ocfg.nx]) for p in P])
+    if shard:
+        lo, hi = shard
+        return ocfg, hi - lo, P[lo:hi], W0[lo:hi]
     return ocfg, B, P, W0
 
 
@@ -129,11 +146,11 @@ def timed_solves(solver, dP, dW0, steps, warmup, barrier):
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
 
 
-def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id):
+def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id, wname="six"):
     fl_iter = algorithmic_flops_per_iter(ocfg)
     flops_launch = float(sum_iters) * fl_iter
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
-    # the kernel nmpc_solve_batch picked for this team size and batch, as the library reports it (nmpc_debug_kernel_choice):
+    # the kernel nmpc_solve_batch picked for this team size and batch, as the library reports it (nmpc_query):
     # 3 column-per-lane (throughput batches), 2 element-per-lane (latency shapes), 1 HBM-resident fallback
     kname = {3: "nmpc::solve_col_kernel<%d,...>", 2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % ocfg.m
     rl = {"bound": "fp64-valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -147,14 +164,15 @@ def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id):
     # iteration and scaled by the iterations of THIS launch.  The profile is stamped with the source hash of the library it was
     # taken from: null unless this run's library is that very build and the workload matches.
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "current", "hbm_traffic.json")))
+        pdir = PROFILE_DIR.get(wname, "current")
+        tj = json.load(open(os.path.join(ROOT, "profiles", pdir, "hbm_traffic.json")))
         same_lib = tj.get("library_src_hash") and ("src=" + tj["library_src_hash"]) in lib_version
         if same_lib and tj["workload"].get("m") == ocfg.m and tj["workload"].get("N") == ocfg.N and tj["workload"].get("batch_per_gpu") == B:
             rl["traffic"] = tj["hbm_bytes_per_iteration"] * float(sum_iters)
-            rl["traffic_source"] = "profiles/current/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch" % tj["library_src_hash"]
+            rl["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch" % (pdir, tj["library_src_hash"])
             rl["traffic_GBps"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9
         else:
-            rl["traffic_source"] = "null: profiles/current/hbm_traffic.json was taken from another build or workload (src=%s)" % tj.get("library_src_hash")
+            rl["traffic_source"] = "null: profiles/%s/hbm_traffic.json was taken from another build or workload (src=%s)" % (pdir, tj.get("library_src_hash"))
     except (OSError, KeyError, ValueError):
         pass
     return rl
@@ -171,6 +189,8 @@ def main():
     ap.add_argument("--closed-loop", type=int, default=20, help="warm closed-loop steps reported as an extra (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances for the CPU baseline (0 = skip)")
     ap.add_argument("--sweep", type=int, default=-1, help="north-star sweep entries (default: on for --gpus 1, 0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: every rank its own batch (default); strong: one global batch, sharded")
+    ap.add_argument("--batch-total", type=int, default=0, help="--scaling strong: instances of the global batch (default: the workload's BASELINE batch)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -208,10 +228,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ocfg, B, P, W0 = make_batch(args.workload, rank, args.batch)
+    if args.scaling == "strong":
+        total = args.batch_total or STRONG_TOTAL[args.workload]
+        ocfg, B, P, W0 = make_batch(args.workload, rank, total, shard=nmpc_amd.shard_range(total, rank, world))
+    else:
+        total = None
+        ocfg, B, P, W0 = make_batch(args.workload, rank, args.batch)
     cfg = Hh.to_product_cfg(ocfg, max_iter=args.max_iter)
     solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
-    kernel_id = int(solver.lib.nmpc_debug_kernel_choice(solver._h, B))
+    kernel_id = int(solver.kernel_for_batch(B))
     dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
     dt, kern_ms, r = timed_solves(solver, dP, dW0, args.steps, args.warmup, barrier)
 
@@ -219,7 +244,7 @@ def main():
     # ---- the result gather of SURVEY.md 8(e): all_gather of w_out / status / iters of every rank's shard, timed on its own
     gather_ms = 0.0
     if world > 1:
-        Bg = B * world
+        Bg = total if total is not None else B * world      # strong: the shards of the global batch (sizes may differ by one)
         torch.cuda.synchronize()
         for rep in range(4):          # first repetition warms the communicator up
             barrier()
@@ -231,9 +256,9 @@ def main():
             if rep:
                 gather_ms += (time.perf_counter() - tg) * 1e3 / 3.0
         assert gw.shape == (Bg, cfg.n_var) and gs.shape == (Bg, 1) and gi.shape == (Bg, 1)
-        lo = rank * B
+        lo = nmpc_amd.shard_range(Bg, rank, world)[0]
         assert torch.equal(gw[lo: lo + B].to(r["x"].device), r["x"]), "gathered shard differs from the local result"
-    stats = torch.tensor([dt, float(iters.sum()), float((status == 0).sum()), float(iters.max()), float(kkt[status == 0].max() if (status == 0).any() else 0.0), kern_ms, gather_ms],
+    stats = torch.tensor([dt, float(iters.sum()), float((status == 0).sum()), float(iters.max()), float(kkt[status == 0].max() if (status == 0).any() else 0.0), kern_ms, gather_ms, float(B)],
                          dtype=torch.float64, device="cuda")
     if world > 1:
         if rehearsal:
@@ -248,21 +273,22 @@ def main():
             dist.destroy_process_group()
         return
     t_max = float(allst[:, 0].max())
-    total_solves = float(B) * world * args.steps
+    n_inst = float(allst[:, 7].sum())                 # instances of all ranks (weak: B per rank; strong: the shards of one global batch)
+    total_solves = n_inst * args.steps
     value = total_solves / t_max
     sum_iters = float(allst[:, 1].sum())
     out = {
         "metric": "NMPC solves/sec (batched swarms), N_robots=%d, N=%d" % (ocfg.m, ocfg.N),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d per GPU, cold start" %
-                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "m": ocfg.m, "N": ocfg.N, "batch_per_gpu": B, "max_iter": args.max_iter, "tol": cfg.tol,
+                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "m": ocfg.m, "N": ocfg.N, "batch_per_gpu": B, "batch_total": int(n_inst), "max_iter": args.max_iter, "tol": cfg.tol,
                    "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
         "library": lib_version,
-        "solve_stats": {"mean_iters": sum_iters / (B * world), "max_iters": float(allst[:, 3].max()),
-                        "converged_frac": float(allst[:, 2].sum()) / (B * world), "max_kkt_converged": float(allst[:, 4].max())},
-        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version, kernel_id),
+        "solve_stats": {"mean_iters": sum_iters / n_inst, "max_iters": float(allst[:, 3].max()),
+                        "converged_frac": float(allst[:, 2].sum()) / n_inst, "max_kkt_converged": float(allst[:, 4].max())},
+        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version, kernel_id, args.workload),
     }
     if world > 1:
         per_rank_bytes = B * (cfg.n_var * 8 + 8)
@@ -303,8 +329,10 @@ def main():
     if world == 1 and do_sweep:
         del solver
         out["sweep"] = []
-        for name in ("two", "ten20", "ten", "composite"):
-            oc2, B2, P2, W2 = make_batch(name, 0)
+        # (workload, batch; 0 = the workload's own): the four north-star shapes, then ten robots at N=30 with the whole BASELINE batch on one
+        # GPU (what strong sharding to 512 per GPU is compared with) and six robots at B=16384, where the launch outgrows its longest solve
+        for name, bsz in (("two", 0), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):
+            oc2, B2, P2, W2 = make_batch(name, 0, bsz)
             c2 = Hh.to_product_cfg(oc2, max_iter=args.max_iter)
             s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
             d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)
@@ -313,7 +341,7 @@ def main():
                                  "m": oc2.m, "N": oc2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
                                  "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
                                  "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
-                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version, int(s2.lib.nmpc_debug_kernel_choice(s2._h, B2)))})
+                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
             del s2
             torch.cuda.empty_cache()
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
@@ -335,32 +363,50 @@ def main():
         dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
         itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
         alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
-        # per iteration the kernel reads or writes the state-sized arrays of its workspace a fixed number of times;
-        # the model below counts those passes (doubles per instance and iteration) from the kernel source
-        nV = (lc.N + 1) * lc.ns
-        ws_doubles_per_iter = 30.0 * nV          # ~30 passes over state-sized arrays (V, slacks, duals, step, trial point) per iteration incl. 1.3 merit evaluations
+        # Algorithmic flops per interior-point iteration of the LIDAR-state NLP, the same dense-Riccati count as SURVEY.md
+        # 8(d) applied to what the kernel factors: the 3-state / 2-control pose recursion (the R distance states of a stage are eliminated
+        # through their own linearised rows): F_ric = N (7/3 3^3 + 4 3^2 2 + 2 3 2^2 + 2^3/3); folding the distance rows into the pose block
+        # and recovering their steps: F_fold = N R (2 (3 3 + 3) + 2 3); evaluation / assembly: F_asm = N (22 + 14 R)
+        fl_iter_l = lc.N * ((7.0 / 3.0) * 27 + 4 * 9 * 2 + 2 * 3 * 4 + 8.0 / 3.0) + lc.N * lc.R * 30.0 + lc.N * (22.0 + 14.0 * lc.R)
+        ach = fl_iter_l * float(itl.sum()) / (kl * 1e-3) / 1e12
         out["sweep"].append({"workload": "lidar_v4: 1 robot, 13 states (pose + 10 ray distances), N=100, Nc=50, batch=%d, cold start" % Bl,
                              "m": 1, "N": lc.N, "batch": Bl, "value": Bl * 2 / dl, "unit": "solves/s", "ms_per_step": 1e3 * dl / 2,
                              "mean_iters": float(itl.mean()), "max_iters": float(itl.max()), "converged_frac": float((stl == 0).mean()),
                              "status_counts": {str(k): int((stl == k).sum()) for k in np.unique(stl)},
-                             "roofline": {"bound": "hbm", "kernel": "nmpc_lidar::lidar_solve_kernel", "kernel_ms": kl,
-                                          "achieved": ws_doubles_per_iter * 8.0 * float(itl.sum()) / (kl * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": ws_doubles_per_iter * 8.0 * float(itl.sum()) / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "roofline": {"bound": "fp64-valu", "kernel": "nmpc_lidar::lidar_solve_kernel", "kernel_ms": kl,
+                                          "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                                          "flops_per_iteration": fl_iter_l, "flops_per_launch": fl_iter_l * float(itl.sum()),
                                           "algorithmic_bytes_per_launch": alg_bytes,
-                                          "note": "achieved = modelled workspace traffic (30 state-sized array passes per iteration x iterations), not PMC; "
-                                                  "the kernel is latency-bound (two serial recursions over 100 stages per iteration), not bandwidth-bound"}})
-        # PMC traffic of the LIDAR kernel (profiles/r2_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
+                                          "hbm_frac_of_algorithmic_bytes": alg_bytes / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "algorithmic flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5), priced against "
+                                                  "the fp64 vector peak like the main kernel; the kernel is latency-bound (two serial recursions over 100 stages per "
+                                                  "iteration, one wavefront per instance): the fraction says how far"}})
+        # PMC traffic of the LIDAR kernel (profiles/current_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
         try:
-            tjl = json.load(open(os.path.join(ROOT, "profiles", "r2_lidar", "hbm_traffic.json")))
+            tjl = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR["lidar"], "hbm_traffic.json")))
             rll = out["sweep"][-1]["roofline"]
             if tjl.get("library_src_hash") and ("src=" + tjl["library_src_hash"]) in lib_version and tjl["workload"].get("batch_per_gpu") == Bl:
                 rll["traffic"] = tjl["hbm_bytes_per_iteration"] * float(itl.sum())
                 rll["traffic_GBps"] = rll["traffic"] / (kl * 1e-3) / 1e9
-                rll["traffic_source"] = "profiles/r2_lidar/hbm_traffic.json@src=%s: PMC bytes per iteration x iterations of this launch" % tjl["library_src_hash"]
+                rll["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration x iterations of this launch" % (PROFILE_DIR["lidar"], tjl["library_src_hash"])
             else:
-                rll["traffic_source"] = "null: profiles/r2_lidar/hbm_traffic.json was taken from another build or batch (src=%s)" % tjl.get("library_src_hash")
+                rll["traffic_source"] = "null: profiles/%s/hbm_traffic.json was taken from another build or batch (src=%s)" % (PROFILE_DIR["lidar"], tjl.get("library_src_hash"))
         except (OSError, KeyError, ValueError):
             pass
+        # CPU baseline of the LIDAR workload: the C oracle (oracle/lidar_oracle.c, OpenMP one instance per thread) on a bounded sample
+        if args.cpu_sample != 0:
+            from oracle import oracle_lib as OL
+            coresl = OL.max_threads()
+            nl = min(Bl, 4 * coresl)
+            OL.lidar_solve_batch(lc, Pl[:coresl], Wl[:coresl], lbx=lbx, ubx=ubx)
+            t1 = time.perf_counter()
+            refl = OL.lidar_solve_batch(lc, Pl[:nl], Wl[:nl], lbx=lbx, ubx=ubx)
+            t_cpul = time.perf_counter() - t1
+            dwl = np.max(np.abs(rl_["x"][:nl].cpu().numpy() - refl["x"]), axis=1)
+            out["sweep"][-1]["cpu_baseline"] = {"value": nl / t_cpul, "unit": "solves/s", "cores": coresl, "kind": "port",
+                                                "sample": "first %d instances of the same batch, OpenMP one instance per thread, %.2f s; CPU restatement "
+                                                          "(oracle/lidar_oracle.c), not CasADi/IPOPT" % (nl, t_cpul),
+                                                "mean_iters": float(refl["iters"].mean()), "same_point_frac_vs_gpu": float((dwl <= 1e-6).mean())}
         del ls
         torch.cuda.empty_cache()
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)

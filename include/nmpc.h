@@ -13,7 +13,8 @@
  *     t0, u0 = shift(T, t0, u)                                   C6:160-169,450
  * Each entry point below names the block it replaces.  All buffers are caller-owned
  * DEVICE pointers (fp64 / int32), row-major with the batch index leading.  No global
- * state; every call is ordered on the hipStream_t passed as `void *stream` (NULL = the
+ * state (the library reads no environment variable; what is not a literal of a reference
+ * script is an explicit nmpc_options_t); every call is ordered on the hipStream_t passed as `void *stream` (NULL = the
  * default stream).  Return value: 0 on success, negative NMPC_E_* on argument / HIP
  * errors.  Non-convergence is NOT an error (the reference never reads solver.stats());
  * it is reported per instance in `status`.
@@ -96,6 +97,29 @@ void nmpc_config_default(nmpc_config_t *cfg, int32_t m, int32_t N);
  */
 int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t **out);
 int32_t nmpc_destroy(nmpc_handle_t *h);
+
+/*
+ * Creation options that are not literals of a reference script.  nmpc_create(cfg, B, out) is nmpc_create_opts(cfg, B, NULL, out).
+ */
+typedef struct nmpc_options {
+    int32_t kernel;         /* 0: the library picks the solve kernel per batch size (default).  1 HBM-resident, 2 element-per-lane,
+                               3 column-per-lane: that kernel for every batch size it can run (tests and A/B measurements)          */
+    int32_t trace_instance; /* -DNMPC_PROFILE builds: instance whose per-iteration trace is recorded (include/nmpc_debug.h); -1 none */
+} nmpc_options_t;
+int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out);
+
+/*
+ * Facts about a handle.  Returns the value, or a negative NMPC_E_* code.
+ *   NMPC_QUERY_KERNEL_FOR_BATCH  arg = B: the solve kernel nmpc_solve_batch launches for a batch of B (1 / 2 / 3 as in nmpc_options_t)
+ *   NMPC_QUERY_WORKSPACE_BYTES   device workspace held by the handle (same as nmpc_workspace_bytes)
+ *   NMPC_QUERY_LDS_BYTES         arg = B: dynamic LDS per swarm instance of that kernel (0 for the HBM-resident kernel's fixed carve-up)
+ *   NMPC_QUERY_MAX_BATCH         the max_batch the handle was created for
+ */
+#define NMPC_QUERY_KERNEL_FOR_BATCH 1
+#define NMPC_QUERY_WORKSPACE_BYTES 2
+#define NMPC_QUERY_LDS_BYTES 3
+#define NMPC_QUERY_MAX_BATCH 4
+int64_t nmpc_query(const nmpc_handle_t *h, int32_t what, int64_t arg);
 
 /* bytes of device workspace held by the handle */
 int64_t nmpc_workspace_bytes(const nmpc_handle_t *h);

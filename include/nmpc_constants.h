@@ -1,0 +1,27 @@
+/*
+ * nmpc_constants.h — constants of the interior-point algorithm that the HIP kernels (csrc/) and the CPU oracles (oracle/) must
+ * agree on: the GPU parity tests assert equal statuses and (almost everywhere) equal iteration counts, so a constant that differed
+ * between the two sides would make them diverge silently.  One definition, included by csrc/nmpc_device.h, csrc/nmpc_lidar.hip,
+ * oracle/nmpc_oracle.c and oracle/lidar_oracle.c.  Plain C preprocessor constants, no dependencies.
+ */
+#ifndef NMPC_CONSTANTS_H_
+#define NMPC_CONSTANTS_H_
+
+/* Inertia correction: factor between consecutive trial shifts of one iteration once a previous iteration needed a shift (IPOPT's
+   kappa_w^+ = 8).  Measured with 4: the literal antipodal swap drops from 113 to 67 iterations, but the warm closed loop
+   falls from 148.8 k to 110.8 k solves/s and the composite from 17.1 k to 12.0 k: kept at 8. */
+#ifndef NMPC_SHIFT_ESCALATION
+#define NMPC_SHIFT_ESCALATION 8.0
+#endif
+
+/* Cold-start retry (restoration of last resort): a solve that stalls after its barrier restarts, fails numerically or is
+   still iterating NMPC_COLD_RETRY_ITERS iterations into an attempt is restarted from the reference's cold start X_k = x0, U = 0
+   (C6:398-400; LIDAR: V4:184-196), at most NMPC_COLD_RETRIES times, the second time with a ten times larger initial barrier parameter. */
+#define NMPC_COLD_RETRY_ITERS 500
+#define NMPC_COLD_RETRIES 2
+
+/* Slack of the stage-0 feasibility pre-check (status 3): a measured x0 that violates a pair / obstacle row by less than this — the
+   previous period's plan holds its rows to the solve tolerance only — is not reported as infeasible. */
+#define NMPC_X0_TOL 1e-6
+
+#endif /* NMPC_CONSTANTS_H_ */

@@ -6,7 +6,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("NMPC_SO") or os.path.join(HERE, "libnmpc_hip.so")      # NMPC_SO: development (A/B builds in one GPU session)
+ROOT = os.path.dirname(HERE)
+# the library lives at the short in-tree path <repo>/lib/libnmpc_hip.so (the package directory's own name is ~115 characters long;
+# tools that record which shared objects a process mapped truncate such paths).  NMPC_SO: development (A/B builds in one GPU session)
+SO_PATH = os.environ.get("NMPC_SO") or os.path.join(ROOT, "lib", "libnmpc_hip.so")
 
 NMPC_MAX_ROBOTS = 10
 NMPC_MAX_OBSTACLES = 8
@@ -17,7 +20,9 @@ ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMP
 
 LIDAR_EXPORTS = ["nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p", "nmpc_lidar_create", "nmpc_lidar_destroy", "nmpc_lidar_solve_batch",
                  "nmpc_lidar_eval_batch", "nmpc_lidar_shift_batch"]
-EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_destroy",
+DEBUG_EXPORTS = ["nmpc_debug_profile", "nmpc_debug_trace", "nmpc_debug_trace2", "nmpc_debug_workspace"]      # include/nmpc_debug.h
+QUERY_KERNEL_FOR_BATCH, QUERY_WORKSPACE_BYTES, QUERY_LDS_BYTES, QUERY_MAX_BATCH = 1, 2, 3, 4
+EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_create_opts", "nmpc_query", "nmpc_destroy",
            "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
 
 
@@ -29,6 +34,11 @@ class CConfig(C.Structure):
                 ("rob_dim", C.c_double), ("margin", C.c_double), ("pad_value", C.c_double),
                 ("obs", C.c_double * (3 * NMPC_MAX_OBSTACLES)), ("tol", C.c_double), ("mu_init", C.c_double),
                 ("max_iter", C.c_int32), ("pair_rows", C.c_int32)]
+
+
+class COptions(C.Structure):
+    """nmpc_options_t"""
+    _fields_ = [("kernel", C.c_int32), ("trace_instance", C.c_int32)]
 
 
 class CLidarConfig(C.Structure):
@@ -60,6 +70,12 @@ def load():
         getattr(L, f).argtypes = [cp]; getattr(L, f).restype = i32
     L.nmpc_config_default.argtypes = [cp, i32, i32]; L.nmpc_config_default.restype = None
     L.nmpc_create.argtypes = [cp, i32, C.POINTER(vp)]; L.nmpc_create.restype = i32
+    L.nmpc_create_opts.argtypes = [cp, i32, C.POINTER(COptions), C.POINTER(vp)]; L.nmpc_create_opts.restype = i32
+    L.nmpc_query.argtypes = [vp, i32, C.c_int64]; L.nmpc_query.restype = C.c_int64
+    L.nmpc_debug_profile.argtypes = [vp, C.POINTER(C.c_int64), i32]; L.nmpc_debug_profile.restype = i32
+    L.nmpc_debug_trace.argtypes = [vp, vp, i32]; L.nmpc_debug_trace.restype = i32
+    L.nmpc_debug_trace2.argtypes = [vp, vp, i32]; L.nmpc_debug_trace2.restype = i32
+    L.nmpc_debug_workspace.argtypes = [vp, i32, vp, C.c_int64, vp]; L.nmpc_debug_workspace.restype = C.c_int64
     L.nmpc_destroy.argtypes = [vp]; L.nmpc_destroy.restype = i32
     L.nmpc_workspace_bytes.argtypes = [vp]; L.nmpc_workspace_bytes.restype = C.c_int64
     L.nmpc_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch.restype = i32

@@ -6,10 +6,13 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SO = os.path.join(HERE, "libnmpc_hip.so")
+LIBDIR = os.path.join(ROOT, "lib")                # short in-tree path (see _lib.SO_PATH)
+SO = os.path.join(LIBDIR, "libnmpc_hip.so")
+INFO = os.path.join(LIBDIR, "build_info.json")    # what the last build() call did: compiled or reused, and the source hash
 SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_lidar.hip", "nmpc_api.cpp"]
-DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h", os.path.join("..", "..", "include", "nmpc.h"), os.path.join("..", "..", "include", "nmpc_lidar.h")]
+DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h"] + [os.path.join("..", "..", "include", h) for h in ("nmpc.h", "nmpc_lidar.h", "nmpc_constants.h", "nmpc_debug.h")]
 
 
 def _hipcc() -> str:
@@ -52,9 +55,34 @@ def needs_build() -> bool:
     return built_hash() != source_hash()
 
 
+def _record(mode: str, seconds: float) -> None:
+    import json
+    import time
+    os.makedirs(LIBDIR, exist_ok=True)
+    info = {"mode": mode, "src_hash": source_hash(), "library": SO, "seconds": round(seconds, 2), "unix_time": time.time(),
+            "hipcc": _hipcc() if mode == "compiled" else None}
+    with open(INFO, "w") as f:
+        json.dump(info, f)
+    print("[nmpc build] %s libnmpc_hip.so src=%s (%.1f s)" % (mode, info["src_hash"], seconds), flush=True)
+
+
+def last_build_info() -> dict:
+    """what the last build() call in this tree did ({} if none was recorded)"""
+    import json
+    try:
+        with open(INFO) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    import time
+    t0 = time.time()
     if not force and not needs_build():
+        _record("reused", time.time() - t0)
         return SO
+    os.makedirs(LIBDIR, exist_ok=True)
     flags = ["--offload-arch=gfx950", os.environ.get("NMPC_OPT", "-O3"), "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="%s"' % source_hash()]
     if os.environ.get("NMPC_PROFILE"):
         flags.append("-DNMPC_PROFILE")
@@ -84,6 +112,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(cc, SOURCES))
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs, cwd=CSRC)
+    _record("compiled", time.time() - t0)
     return SO
 
 

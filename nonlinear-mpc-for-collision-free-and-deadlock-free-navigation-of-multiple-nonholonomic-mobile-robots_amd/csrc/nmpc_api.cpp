@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "nmpc_device.h"
+#include "../../include/nmpc_debug.h"
 
 struct nmpc_handle {
     nmpc_config_t cfg;
@@ -89,9 +90,12 @@ static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
     return 0;
 }
 
-int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t **out)
+int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t **out) { return nmpc_create_opts(cfg, max_batch, nullptr, out); }
+
+int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out)
 {
     if (!cfg || !out || max_batch < 1) return NMPC_E_ARG;
+    if (opts && (opts->kernel < 0 || opts->kernel > 3)) return NMPC_E_ARG;
     if (cfg->N < 2 || cfg->N > 4096 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
     if (!(cfg->T > 0.0) || !(cfg->v_max > 0.0) || !(cfg->w_max > 0.0) || !(cfg->xy_max > 0.0) || !(cfg->th_max > 0.0)) return NMPC_E_ARG;
     if (!(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0) return NMPC_E_ARG;
@@ -110,12 +114,12 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     h->cfg = *cfg;
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
-    const char *kv = getenv("NMPC_KERNEL");
-    h->kernel = (kv && kv[0] >= '1' && kv[0] <= '3') ? kv[0] - '0' : 3;
+    const int pin = opts ? opts->kernel : 0;      // 0: chosen per batch size (kernel_for_batch)
+    h->kernel = pin ? pin : 3;
     // horizons whose iterate does not fit the 160 KB of LDS of a CU run on the HBM-resident kernel (same algorithm, slower)
     if (h->kernel == 3 && nmpc::col_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 2;
     if (h->kernel == 2 && nmpc::lds_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 1;
-    h->lat_ok = !(kv && kv[0] == '3') && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
+    h->lat_ok = pin != 3 && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
     nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
     {   // slack / dual arrays of the column kernel: pair, obstacle, control-bound (slacks + duals) and state-bound (duals) rows
         const int64_t N = cfg->N, N1 = N + 1, m = cfg->m, NPd = m * (m - 1) / 2, MK = m * cfg->n_obs, NU = 2 * m, NXB = h->P.nxb;
@@ -130,7 +134,7 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
     (void)hipMemset(h->prof, 0, (12 + 24 * 2048) * sizeof(long long));
     if (hipMalloc((void **)&h->ord_chk, sizeof(int32_t) * ((size_t)max_batch + 1)) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); free(h); return NMPC_E_NOMEM; }
     (void)hipMemset(h->ord_chk, 0, sizeof(int32_t) * ((size_t)max_batch + 1));
-    { const char *ti = getenv("NMPC_TRACE_INST"); h->P.trace_inst = ti ? atoi(ti) : -1; }
+    h->P.trace_inst = opts ? opts->trace_instance : -1;
     *out = h;
     return NMPC_OK;
 }
@@ -225,10 +229,24 @@ int32_t nmpc_odometry_batch(int64_t n, const double *odom, const double *init, d
     return nmpc::launch_odometry((long)n, odom, init, pose, wrap_2pi != 0, (hipStream_t)stream) == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
-/* development aid (not part of include/nmpc.h): the kernel nmpc_solve_batch would launch for a batch of B (1 / 2 / 3, see kernel_for_batch) */
-int32_t nmpc_debug_kernel_choice(nmpc_handle_t *h, int32_t B) { return h ? kernel_for_batch(h, B) : NMPC_E_ARG; }
+int64_t nmpc_query(const nmpc_handle_t *h, int32_t what, int64_t arg)
+{
+    if (!h) return NMPC_E_ARG;
+    switch (what) {
+    case NMPC_QUERY_KERNEL_FOR_BATCH: return (arg < 0 || arg > h->max_batch) ? NMPC_E_ARG : kernel_for_batch(h, (int32_t)arg);
+    case NMPC_QUERY_WORKSPACE_BYTES: return h->ws_bytes;
+    case NMPC_QUERY_LDS_BYTES: {
+        if (arg < 0 || arg > h->max_batch) return NMPC_E_ARG;
+        const int k = kernel_for_batch(h, (int32_t)arg);
+        return k == 3 ? (int64_t)nmpc::col_kernel_bytes(h->P, h->cfg.m) : (k == 2 ? (int64_t)nmpc::lds_kernel_bytes(h->P, h->cfg.m) : 0);
+    }
+    case NMPC_QUERY_MAX_BATCH: return h->max_batch;
+    default: return NMPC_E_ARG;
+    }
+}
 
-/* development aid (not part of include/nmpc.h): per-phase cycle counters of an NMPC_PROFILE build */
+/* ---- development aids, declared in include/nmpc_debug.h (not part of the drop-in boundary) */
+/* per-phase cycle counters of an NMPC_PROFILE build */
 int32_t nmpc_debug_profile(nmpc_handle_t *h, int64_t *out12, int32_t reset)
 {
     if (!h || !out12) return NMPC_E_ARG;
@@ -251,7 +269,7 @@ int32_t nmpc_debug_trace2(nmpc_handle_t *h, double *out, int32_t rows)
     return NMPC_OK;
 }
 
-/* development aid: copy the per-instance workspace of one instance to the host; returns its length in doubles */
+/* copy the per-instance workspace of one instance to the host; returns its length in doubles */
 int64_t nmpc_debug_workspace(nmpc_handle_t *h, int32_t inst, double *out, int64_t cap, int64_t *offs)
 {
     if (!h) return NMPC_E_ARG;

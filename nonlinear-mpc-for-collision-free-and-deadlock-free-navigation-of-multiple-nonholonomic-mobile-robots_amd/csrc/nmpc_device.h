@@ -5,22 +5,8 @@
 
 #include "../../include/nmpc.h"
 
-// inertia correction: factor between consecutive trial shifts of one iteration once a previous iteration needed a shift (IPOPT's
-// kappa_w^+ = 8).  Measured this round with 4: on the cold six-robot bench batch the literal antipodal swap drops from 113
-// to 67 iterations and the 99th percentile from 70 to 63 at the same total number of sweeps (120.7 k vs 117.9 k solves/s), but the warm
-// closed loop falls from 148.8 k to 110.8 k solves/s and the composite from 17.1 k to 12.0 k: kept at 8.  Shared by all kernels.
-#ifndef NMPC_SHIFT_ESCALATION
-#define NMPC_SHIFT_ESCALATION 8.0
-#endif
-
-// Cold-start retry (restoration of last resort): a solve that stalls after its barrier restarts, fails numerically or is still
-// iterating NMPC_COLD_RETRY_ITERS iterations into an attempt is restarted from the reference's cold start X_k = x0, U = 0 (C6:398-400), at most
-// NMPC_COLD_RETRIES times, the second time with a ten times larger initial barrier parameter.  Mirrored in oracle/nmpc_oracle.c.
-#define NMPC_COLD_RETRY_ITERS 500
-#define NMPC_COLD_RETRIES 2
-// slack of the stage-0 feasibility pre-check (status 3): a measured x0 that violates a pair / obstacle row by less than this — the
-// previous period's plan holds its rows to the solve tolerance only — is not reported as infeasible
-#define NMPC_X0_TOL 1e-6
+// shared with the CPU oracles: NMPC_SHIFT_ESCALATION, NMPC_COLD_RETRY_ITERS, NMPC_COLD_RETRIES, NMPC_X0_TOL
+#include "../../include/nmpc_constants.h"
 
 namespace nmpc {
 

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../../include/nmpc_constants.h"      // cold-start retry and inertia constants shared with the main solver and the oracles
 #include "../../include/nmpc_lidar.h"
 
 namespace nmpc_lidar {
@@ -64,9 +65,6 @@ __device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>
 // reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
 // recursion) run uniformly on all lanes, lane 0 storing.
 #define N_LDS_STAGES(N_) ((N_) + 1)
-// cold-start retry: the constants of nmpc_device.h (NMPC_COLD_RETRY_ITERS, NMPC_COLD_RETRIES), mirrored by oracle/lidar_oracle.c
-#define LIDAR_COLD_RETRY_ITERS 500
-#define LIDAR_COLD_RETRIES 2
 #ifndef NMPC_LIDAR_UNROLL
 #define NMPC_LIDAR_UNROLL 4      // stages of the forward / adjoint recursions unrolled together: their LDS operand reads issue as one batch
 #endif
@@ -245,10 +243,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             const double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
             const double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c));
             kkt = E0;
-            if (!(E0 == E0)) { if (n_cold < LIDAR_COLD_RETRIES && it < P.max_iter) { cold_retry(); break; } status = NMPC_STATUS_NUMERIC; break; }
+            if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && it < P.max_iter) { cold_retry(); break; } status = NMPC_STATUS_NUMERIC; break; }
             if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
             if (it >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
-            if (n_cold < LIDAR_COLD_RETRIES && it - it_base >= LIDAR_COLD_RETRY_ITERS) { cold_retry(); break; }
+            if (n_cold < NMPC_COLD_RETRIES && it - it_base >= NMPC_COLD_RETRY_ITERS) { cold_retry(); break; }
             const double mu_min = P.tol / 10.0;
             for (;;) {
                 const double cm = fmax(fabs(cmax - mu), fabs(cmin - mu));
@@ -404,10 +402,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                 if (ok) break;
                 ntry++;
                 if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-                else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+                else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
                 if (delta > 1e20) break;
             }
-            if (!ok) { if (n_cold < LIDAR_COLD_RETRIES) { cold_retry(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
+            if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
             if (delta > 0.0) delta_last = delta;
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
             __syncthreads();
@@ -569,7 +567,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             __syncthreads();
             it++;
             if (n_tiny >= 5) {
-                if (n_restart >= 3) { if (n_cold < LIDAR_COLD_RETRIES) { cold_retry(); break; } status = NMPC_STATUS_STALLED; break; }
+                if (n_restart >= 3) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); break; } status = NMPC_STATUS_STALLED; break; }
                 n_restart++; n_tiny = 0; mu = fmax(mu, P.mu_init); restarting = true;
                 break;
             }
@@ -587,35 +585,40 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     }
 }
 
-// f (V4:135-136) and g = [gx; gd] (V4:151): one thread per (instance, stage); stage N handles the initial rows
-__global__ __launch_bounds__(256) void lidar_eval_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w,
-                                                          double *__restrict__ f_out, double *__restrict__ g_out)
+// f (V4:135-136) and g = [gx; gd] (V4:151): one wavefront per instance, lane = stage (+64, ...); trip k == N handles the initial rows.
+// The objective is summed in a fixed order (per lane over its stages, then a butterfly over the wave): bit-reproducible from run to run.
+__global__ __launch_bounds__(64) void lidar_eval_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w,
+                                                         double *__restrict__ f_out, double *__restrict__ g_out)
 {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
     const int N = P.N, R = P.R, ns = P.ns;
-    if (gid >= (long)B * (N + 1)) return;
-    const int b = (int)(gid / (N + 1)), k = (int)(gid - (long)b * (N + 1));
     const double *X = w + (size_t)b * P.nvar, *U = X + (size_t)(N + 1) * ns, *pp = p_in + (size_t)b * P.np;
     double *gx = g_out ? g_out + (size_t)b * P.ng : nullptr, *gd = g_out ? gx + 3 * (N + 1) : nullptr;
-    if (k == N) {
-        if (g_out) { for (int i = 0; i < 3; i++) gx[i] = X[i] - pp[i]; for (int m = 0; m < R; m++) gd[m] = X[3 + m] - pp[6 + m]; }
-        return;
-    }
-    const double *v = X + (size_t)k * ns, *vn = v + ns, *u = U + 2 * (k < P.Nc - 1 ? k : P.Nc - 1);
-    double fs = P.q[0] * (v[0] - pp[3]) * (v[0] - pp[3]) + P.q[1] * (v[1] - pp[4]) * (v[1] - pp[4]) + P.q[2] * (v[2] - pp[5]) * (v[2] - pp[5]) +
-                P.r[0] * u[0] * u[0] + P.r[1] * u[1] * u[1];
-    if (P.lw != 0.0) for (int m = 0; m < R; m++) fs += P.lw / (v[3 + m] * v[3 + m]);
-    if (g_out) {
-        double s, c;
-        sincos(v[2], &s, &c);
-        gx[3 * (k + 1)] = vn[0] - (v[0] + P.T * u[0] * c); gx[3 * (k + 1) + 1] = vn[1] - (v[1] + P.T * u[0] * s); gx[3 * (k + 1) + 2] = vn[2] - (v[2] + P.T * u[1]);
-        for (int m = 0; m < R; m++) {
-            double sa, ca;
-            sincos(X[2] + pp[6 + R + m], &sa, &ca);       // pObs from the STAGE-0 variables of w (V4:114-118)
-            gd[R * (k + 1) + m] = vn[3 + m] - (fabs(vn[0] - (X[0] + X[3 + m] * ca)) + fabs(vn[1] - (X[1] + X[3 + m] * sa)));
+    double fs = 0.0;
+    for (int k = lane; k <= N; k += 64) {
+        if (k == N) {
+            if (g_out) { for (int i = 0; i < 3; i++) gx[i] = X[i] - pp[i]; for (int m = 0; m < R; m++) gd[m] = X[3 + m] - pp[6 + m]; }
+            continue;
+        }
+        const double *v = X + (size_t)k * ns, *vn = v + ns, *u = U + 2 * (k < P.Nc - 1 ? k : P.Nc - 1);
+        double fk = P.q[0] * (v[0] - pp[3]) * (v[0] - pp[3]) + P.q[1] * (v[1] - pp[4]) * (v[1] - pp[4]) + P.q[2] * (v[2] - pp[5]) * (v[2] - pp[5]) +
+                    P.r[0] * u[0] * u[0] + P.r[1] * u[1] * u[1];
+        if (P.lw != 0.0) for (int m = 0; m < R; m++) fk += P.lw / (v[3 + m] * v[3 + m]);
+        fs += fk;
+        if (g_out) {
+            double s, c;
+            sincos(v[2], &s, &c);
+            gx[3 * (k + 1)] = vn[0] - (v[0] + P.T * u[0] * c); gx[3 * (k + 1) + 1] = vn[1] - (v[1] + P.T * u[0] * s); gx[3 * (k + 1) + 2] = vn[2] - (v[2] + P.T * u[1]);
+            for (int m = 0; m < R; m++) {
+                double sa, ca;
+                sincos(X[2] + pp[6 + R + m], &sa, &ca);       // pObs from the STAGE-0 variables of w (V4:114-118)
+                gd[R * (k + 1) + m] = vn[3 + m] - (fabs(vn[0] - (X[0] + X[3 + m] * ca)) + fabs(vn[1] - (X[1] + X[3 + m] * sa)));
+            }
         }
     }
-    if (f_out) atomicAdd(&f_out[b], fs);
+    for (int o = 32; o > 0; o >>= 1) fs += __shfl_xor(fs, o);
+    if (f_out && lane == 0) f_out[b] = fs;
 }
 
 // warm-start shuffle V4:258-270
@@ -666,8 +669,6 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     h->cfg = *cfg; h->max_batch = max_batch;
     h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3);
     if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU (N ~ 1000 with Nc = N / 2)
-    if (h->lds_bytes > 48 * 1024 &&
-        hipFuncSetAttribute((const void *)nmpc_lidar::lidar_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) { free(h); return NMPC_E_HIP; }
     nmpc_lidar::LParams &P = h->P;
     memset(&P, 0, sizeof(P));
     P.N = N; P.Nc = Nc; P.R = R; P.ns = ns; P.max_iter = cfg->max_iter; P.nvar = nv; P.ng = nmpc_lidar_n_g(cfg); P.np = nmpc_lidar_n_p(cfg);
@@ -725,6 +726,10 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
+    // the dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a handle: set per launch when this handle needs more than HIP's
+    // default of 64 KB (a second handle with another horizon would otherwise change the limit under this one)
+    if (h->lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)nmpc_lidar::lidar_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) return NMPC_E_HIP;
     hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)B), dim3(64), h->lds_bytes, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
@@ -736,9 +741,7 @@ int32_t nmpc_lidar_eval_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p
     if (!p || !w) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    if (f && hipMemsetAsync(f, 0, sizeof(double) * (size_t)B, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
-    const long total = (long)B * (h->P.N + 1);
-    hipLaunchKernelGGL(nmpc_lidar::lidar_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P, B, p, w, f, g);
+    hipLaunchKernelGGL(nmpc_lidar::lidar_eval_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, h->P, B, p, w, f, g);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

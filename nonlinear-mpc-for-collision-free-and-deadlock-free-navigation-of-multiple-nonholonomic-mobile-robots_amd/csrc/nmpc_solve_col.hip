@@ -1338,12 +1338,18 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool du
     return d * sizeof(double);
 }
 // slacks / duals in LDS: up to four robots, when eight instances still share a CU
-template <int M_, int THB> static bool col_duals_in_lds(const KParams &P) { return M_ <= 4 && col_lds_bytes<M_, THB>(P, true) <= 20 * 1024; }
+#ifndef NMPC_COL_DL_MAXM
+#define NMPC_COL_DL_MAXM 4
+#endif
+#ifndef NMPC_COL_DL_BYTES
+#define NMPC_COL_DL_BYTES (20 * 1024)
+#endif
+template <int M_, int THB> static bool col_duals_in_lds(const KParams &P) { return M_ <= NMPC_COL_DL_MAXM && col_lds_bytes<M_, THB>(P, true) <= NMPC_COL_DL_BYTES; }
 
 template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
                                                         int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
 {
-    constexpr int DLmax = (M_ <= 4) ? 1 : 0;
+    constexpr int DLmax = (M_ <= NMPC_COL_DL_MAXM) ? 1 : 0;
     const bool dl = DLmax && col_duals_in_lds<M_, THB>(P);
     size_t lds = col_lds_bytes<M_, THB>(P, dl);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

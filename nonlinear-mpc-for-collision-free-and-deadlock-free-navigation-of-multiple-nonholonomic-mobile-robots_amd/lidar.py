@@ -91,7 +91,8 @@ def lidar_params(cfg: LidarProblemConfig, pose, xs, scan) -> np.ndarray:
 
 
 class LidarSolver:
-    """The object lidar_nlpsol() returns.  Owns the device workspace (structure-of-arrays, one lane per instance)."""
+    """The object lidar_nlpsol() returns.  Owns the device workspace: one contiguous block per instance (the solve kernel runs one
+    wavefront per instance and spreads the stages of the horizon over its lanes)."""
 
     def __init__(self, cfg: LidarProblemConfig, lbx=None, ubx=None, max_batch: int = 1, device: Optional[int] = None):
         import torch

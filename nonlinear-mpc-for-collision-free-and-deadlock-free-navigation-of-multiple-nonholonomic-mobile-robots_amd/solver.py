@@ -84,7 +84,12 @@ def merge_swarm(w1, m: int, N: int):
 class NmpcSolver:
     """The object nlpsol() returns.  Owns a device workspace sized for `max_batch` instances."""
 
-    def __init__(self, cfg: ProblemConfig, max_batch: int = 1, device: Optional[int] = None):
+    def __init__(self, cfg: ProblemConfig, max_batch: int = 1, device: Optional[int] = None, kernel: Optional[int] = None,
+                 trace_instance: Optional[int] = None):
+        """kernel: None / 0 = the library picks the solve kernel per batch size; 1 / 2 / 3 pins the HBM-resident / element-per-lane /
+        column-per-lane kernel (nmpc_options_t).  The library itself reads no environment variable; this host class does, for
+        development: NMPC_KERNEL and NMPC_TRACE_INST supply the two options when the arguments are not given."""
+        import os
         self.cfg = cfg
         self.torch = _torch()
         self.lib = _lib.load()
@@ -93,7 +98,10 @@ class NmpcSolver:
         self._h = C.c_void_p()
         self.max_batch = int(max_batch)
         with self.torch.cuda.device(self.device):
-            _lib.check(self.lib.nmpc_create(C.byref(self._ccfg), self.max_batch, C.byref(self._h)), "nmpc_create")
+            kv = os.environ.get("NMPC_KERNEL", "")
+            opts = _lib.COptions(kernel=int(kernel) if kernel is not None else (int(kv) if kv[:1] in ("1", "2", "3") else 0),
+                                 trace_instance=int(trace_instance) if trace_instance is not None else int(os.environ.get("NMPC_TRACE_INST", "-1")))
+            _lib.check(self.lib.nmpc_create_opts(C.byref(self._ccfg), self.max_batch, C.byref(opts), C.byref(self._h)), "nmpc_create_opts")
         self.n_var, self.n_g, self.n_p = cfg.n_var, cfg.n_g, cfg.n_p
         assert self.n_var == self.lib.nmpc_n_var(C.byref(self._ccfg)) and self.n_g == self.lib.nmpc_n_g(C.byref(self._ccfg))
         self._stats: Dict = {}
@@ -110,6 +118,10 @@ class NmpcSolver:
     @property
     def workspace_bytes(self) -> int:
         return int(self.lib.nmpc_workspace_bytes(self._h))
+
+    def kernel_for_batch(self, B: int) -> int:
+        """the solve kernel nmpc_solve_batch launches for a batch of B: 3 column-per-lane, 2 element-per-lane, 1 HBM-resident (nmpc_query)"""
+        return int(self.lib.nmpc_query(self._h, _lib.QUERY_KERNEL_FOR_BATCH, int(B)))
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

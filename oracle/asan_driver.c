@@ -19,11 +19,11 @@ int32_t nmpc_lidar_oracle_eval_batch(const nmpc_lidar_config_t *, int32_t, const
 static int swarm(int m, int N, int n_obs)
 {
     nmpc_config_t c;
-    nmpc_config_default(&c, m, N);
+    nmpc_oracle_config_default(&c, m, N);
     c.T = 0.3; c.dmin = 0.4; c.v_max = 0.15; c.w_max = 1.5; c.max_iter = 400; c.n_obs = n_obs;
     if (m == 1) { c.pad_rows = 0; c.th_max = 6.283185307179586; }
     for (int o = 0; o < n_obs; o++) { c.obs[3 * o] = 2.0 + o; c.obs[3 * o + 1] = -2.0; c.obs[3 * o + 2] = 0.15; }
-    const int B = 3, nv = nmpc_n_var(&c), ng = nmpc_n_g(&c), nx = 3 * m;
+    const int B = 3, nv = nmpc_oracle_n_var(&c), ng = nmpc_oracle_n_g(&c), nx = 3 * m;
     double *p = calloc((size_t)B * 2 * nx, sizeof(double)), *w0 = calloc((size_t)B * nv, sizeof(double)), *w = calloc((size_t)B * nv, sizeof(double));
     double *wn = calloc((size_t)B * nv, sizeof(double)), *x0n = calloc((size_t)B * nx, sizeof(double)), *g = calloc((size_t)B * ng, sizeof(double));
     double obj[3], kkt[3], f[3]; int32_t st[3], it[3];
@@ -47,7 +47,7 @@ static int swarm(int m, int N, int n_obs)
 static int lidar(int N, int Nc, int R)
 {
     nmpc_lidar_config_t c = {N, Nc, R, 400, 0.075, {1.0, 5.0, 0.1}, {0.5, 0.05}, 0.1, 1e-8, 0.5};
-    const int nv = nmpc_lidar_n_var(&c), ng = nmpc_lidar_n_g(&c), np_ = nmpc_lidar_n_p(&c), ns = 3 + R;
+    const int nv = nmpc_lidar_oracle_n_var(&c), ng = nmpc_lidar_oracle_n_g(&c), np_ = nmpc_lidar_oracle_n_p(&c), ns = 3 + R;
     double *lb = malloc(sizeof(double) * nv), *ub = malloc(sizeof(double) * nv), *p = calloc(np_, sizeof(double)), *w0 = calloc(nv, sizeof(double)), *w = calloc(nv, sizeof(double)),
            *g = calloc(ng, sizeof(double));
     for (int k = 0; k <= N; k++)

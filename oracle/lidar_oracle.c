@@ -29,11 +29,8 @@
 #include <omp.h>
 #endif
 
+#include "../include/nmpc_constants.h"      /* cold-start retry and inertia constants shared with the HIP kernels */
 #include "../include/nmpc_lidar.h"
-
-/* cold-start retry: the constants of csrc/nmpc_device.h (the LIDAR kernel mirrors this file) */
-#define NMPC_COLD_RETRY_ITERS 500
-#define NMPC_COLD_RETRIES 2
 
 #define RMAX NMPC_LIDAR_MAX_RAYS
 #define NS (3 + RMAX)
@@ -358,7 +355,7 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
                 if (ok) break;
                 ntry++;
                 if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-                else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+                else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
                 if (delta > 1e20) break;
             }
             if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { LIDAR_COLD_RETRY(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
@@ -502,15 +499,15 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
     return status;
 }
 
-int32_t nmpc_lidar_n_var(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) + 2 * c->Nc : NMPC_E_ARG; }
-int32_t nmpc_lidar_n_g(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) : NMPC_E_ARG; }
-int32_t nmpc_lidar_n_p(const nmpc_lidar_config_t *c) { return c ? 6 + 2 * c->R : NMPC_E_ARG; }
+int32_t nmpc_lidar_oracle_n_var(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) + 2 * c->Nc : NMPC_E_ARG; }
+int32_t nmpc_lidar_oracle_n_g(const nmpc_lidar_config_t *c) { return c ? (3 + c->R) * (c->N + 1) : NMPC_E_ARG; }
+int32_t nmpc_lidar_oracle_n_p(const nmpc_lidar_config_t *c) { return c ? 6 + 2 * c->R : NMPC_E_ARG; }
 
 int32_t nmpc_lidar_oracle_solve_batch(const nmpc_lidar_config_t *cfg, const double *lbx, const double *ubx, int32_t B, const double *p, const double *w0,
                                       double *w_out, double *obj, int32_t *status, int32_t *iters, double *kkt, int32_t nthreads)
 {
     if (!cfg || cfg->R < 0 || cfg->R > RMAX || cfg->N < 1 || cfg->Nc < 1 || cfg->Nc > cfg->N) return NMPC_E_ARG;
-    const int nv = nmpc_lidar_n_var(cfg), np_ = nmpc_lidar_n_p(cfg);
+    const int nv = nmpc_lidar_oracle_n_var(cfg), np_ = nmpc_lidar_oracle_n_p(cfg);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -536,7 +533,7 @@ int32_t nmpc_lidar_oracle_solve_batch(const nmpc_lidar_config_t *cfg, const doub
 /* f (V4:135-136) and g = [gx; gd] (V4:151) in the reference's order */
 int32_t nmpc_lidar_oracle_eval_batch(const nmpc_lidar_config_t *cfg, int32_t B, const double *p, const double *wv, double *f, double *g)
 {
-    const int N = cfg->N, R = cfg->R, ns = 3 + R, nv = nmpc_lidar_n_var(cfg), ng = nmpc_lidar_n_g(cfg), np_ = nmpc_lidar_n_p(cfg);
+    const int N = cfg->N, R = cfg->R, ns = 3 + R, nv = nmpc_lidar_oracle_n_var(cfg), ng = nmpc_lidar_oracle_n_g(cfg), np_ = nmpc_lidar_oracle_n_p(cfg);
     for (int b = 0; b < B; b++) {
         const double *X = wv + (size_t)b * nv, *U = X + (size_t)(N + 1) * ns, *pp = p + (size_t)b * np_;
         double *gx = g ? g + (size_t)b * ng : NULL, *gd = g ? gx + 3 * (N + 1) : NULL;

@@ -39,6 +39,7 @@
  * parallel with OpenMP (one instance per thread).
  */
 #include "../include/nmpc.h"
+#include "../include/nmpc_constants.h"      /* NMPC_SHIFT_ESCALATION, NMPC_COLD_RETRY_ITERS, NMPC_COLD_RETRIES, NMPC_X0_TOL: shared with the HIP kernels */
 
 #include <math.h>
 #include <stdio.h>
@@ -48,13 +49,6 @@
 #include <omp.h>
 #endif
 
-/* iterations of one attempt after which a solve that has not converged is restarted from the cold start, and the number of such
-   restarts (the second one with a ten times larger initial barrier parameter); also in csrc/nmpc_device.h */
-#define NMPC_COLD_RETRY_ITERS 500
-#define NMPC_COLD_RETRIES 2
-/* slack of the stage-0 feasibility pre-check: a measured x0 that violates a pair / obstacle row by less than this (the previous
-   period's plan holds its rows to the solve tolerance only) is not reported as infeasible */
-#define NMPC_X0_TOL 1e-6
 
 #define NXM (3 * NMPC_MAX_ROBOTS)
 #define NUM_ (2 * NMPC_MAX_ROBOTS)
@@ -81,15 +75,15 @@ typedef struct {
     double *Hxx, *gx, *huu, *gu, *hvt, *Kg, *kff;
 } ws_t;
 
-int32_t nmpc_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * c->m * c->N; }
-int32_t nmpc_n_p(const nmpc_config_t *c) { return 6 * c->m; }
-int32_t nmpc_n_g(const nmpc_config_t *c)
+int32_t nmpc_oracle_n_var(const nmpc_config_t *c) { return 3 * c->m * (c->N + 1) + 2 * c->m * c->N; }
+int32_t nmpc_oracle_n_p(const nmpc_config_t *c) { return 6 * c->m; }
+int32_t nmpc_oracle_n_g(const nmpc_config_t *c)
 {
     int M = c->pair_rows ? c->m * (c->m - 1) / 2 : 0;   /* pair_rows = 0: AS/mpc_online_casadi_tb3_multi_centralized.py:115-148 */
     return 3 * c->m + (c->pad_rows ? M : 0) + (3 * c->m + M + c->m * c->n_obs) * c->N;
 }
 
-void nmpc_config_default(nmpc_config_t *c, int32_t m, int32_t N)
+void nmpc_oracle_config_default(nmpc_config_t *c, int32_t m, int32_t N)
 {
     memset(c, 0, sizeof(*c));
     c->m = m; c->N = N; c->n_obs = 0; c->pad_rows = m > 1;
@@ -583,7 +577,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             if (ok) break;
             ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-            else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
+            else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
         }
         if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { COLD_RETRY(); it++; continue; } status = NMPC_STATUS_NUMERIC; break; }
@@ -766,7 +760,7 @@ int32_t nmpc_oracle_solve_batch(const nmpc_config_t *cfg, int32_t B, const doubl
                                 int32_t *status, int32_t *iters, double *kkt, int32_t nthreads)
 {
     if (!cfg || cfg->m < 1 || cfg->m > NMPC_MAX_ROBOTS || cfg->N < 1 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
-    const int nv = nmpc_n_var(cfg), np_ = nmpc_n_p(cfg);
+    const int nv = nmpc_oracle_n_var(cfg), np_ = nmpc_oracle_n_p(cfg);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -793,7 +787,7 @@ int32_t nmpc_oracle_solve_batch(const nmpc_config_t *cfg, int32_t B, const doubl
 int32_t nmpc_oracle_eval_batch(const nmpc_config_t *cfg, int32_t B, const double *p, const double *wv, double *f, double *g)
 {
     const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, M = cfg->pair_rows ? m * (m - 1) / 2 : 0, K = cfg->n_obs;
-    const int nv = nmpc_n_var(cfg), ng = nmpc_n_g(cfg);
+    const int nv = nmpc_oracle_n_var(cfg), ng = nmpc_oracle_n_g(cfg);
     for (int b = 0; b < B; b++) {
         const double *X = wv + (size_t)b * nv, *U = X + (size_t)(N + 1) * nx, *pp = p + (size_t)b * 2 * nx;
         double fv = 0.0;
@@ -836,7 +830,7 @@ int32_t nmpc_oracle_eval_batch(const nmpc_config_t *cfg, int32_t B, const double
 int32_t nmpc_oracle_shift_batch(const nmpc_config_t *cfg, int32_t B, const double *p_in, const double *w_in, double *w_next,
                                 double *x0_next)
 {
-    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, nv = nmpc_n_var(cfg);
+    const int m = cfg->m, N = cfg->N, nx = 3 * m, nu = 2 * m, nv = nmpc_oracle_n_var(cfg);
     for (int b = 0; b < B; b++) {
         const double *X = w_in + (size_t)b * nv, *U = X + (size_t)(N + 1) * nx;
         double *Xn = w_next + (size_t)b * nv, *Un = Xn + (size_t)(N + 1) * nx;

@@ -27,8 +27,8 @@ class Config(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libnmpc_oracle.so")
     src = os.path.join(_HERE, "nmpc_oracle.c")
-    hdr = os.path.join(_HERE, "..", "include", "nmpc.h")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("nmpc.h", "nmpc_constants.h")]
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libnmpc_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -43,7 +43,7 @@ def lib():
         _LIB.nmpc_oracle_eval_batch.argtypes = [C.POINTER(Config), C.c_int32, dp, dp, dp, dp]
         _LIB.nmpc_oracle_shift_batch.argtypes = [C.POINTER(Config), C.c_int32, dp, dp, dp, dp]
         _LIB.nmpc_oracle_max_threads.restype = C.c_int32
-        for f in ("nmpc_n_var", "nmpc_n_g", "nmpc_n_p"):
+        for f in ("nmpc_oracle_n_var", "nmpc_oracle_n_g", "nmpc_oracle_n_p"):
             getattr(_LIB, f).argtypes = [C.POINTER(Config)]
             getattr(_LIB, f).restype = C.c_int32
     return _LIB
@@ -72,7 +72,7 @@ def solve_batch(cfg: Config, p: np.ndarray, w0: np.ndarray, nthreads: int = 0):
     L = lib()
     p = np.ascontiguousarray(p, dtype=np.float64); w0 = np.ascontiguousarray(w0, dtype=np.float64)
     B = p.shape[0]
-    nv = L.nmpc_n_var(C.byref(cfg))
+    nv = L.nmpc_oracle_n_var(C.byref(cfg))
     assert p.shape == (B, 6 * cfg.m) and w0.shape == (B, nv)
     w = np.empty((B, nv)); obj = np.empty(B); kkt = np.empty(B)
     st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)
@@ -86,7 +86,7 @@ def eval_batch(cfg: Config, p: np.ndarray, w: np.ndarray):
     L = lib()
     p = np.ascontiguousarray(p, dtype=np.float64); w = np.ascontiguousarray(w, dtype=np.float64)
     B = p.shape[0]
-    ng = L.nmpc_n_g(C.byref(cfg))
+    ng = L.nmpc_oracle_n_g(C.byref(cfg))
     f = np.empty(B); g = np.empty((B, ng))
     L.nmpc_oracle_eval_batch(C.byref(cfg), B, _dp(p), _dp(w), _dp(f), _dp(g))
     return f, g
@@ -120,8 +120,8 @@ def lidar_lib():
     if _LLIB is None:
         so = os.path.join(_HERE, "liblidar_oracle.so")
         src = os.path.join(_HERE, "lidar_oracle.c")
-        hdr = os.path.join(_HERE, "..", "include", "nmpc_lidar.h")
-        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("nmpc_lidar.h", "nmpc_constants.h")]
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs)):
             subprocess.check_call(["make", "-C", _HERE, "-B", "liblidar_oracle.so"], stdout=subprocess.DEVNULL)
         _LLIB = C.CDLL(so)
         dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)

@@ -49,7 +49,49 @@ def make(name, cfg, P):
                         f=np.array([r[3] for r in rows]), w_pol=np.stack([r[4] for r in rows]), f_pol=np.array([r[5] for r in rows]))
 
 
+def lidar_cases():
+    """(name, LidarConfig, pose, goal) of tests/golden/slsqp_lidar.npz: three triples with aligned bounds and one with the bounds exactly as
+    the script builds them (V4:161-176: misaligned with its own packing — from some stage on the POSE entries carry the distance
+    bounds [0.15, 10])."""
+    from oracle import lidar_ref as LR
+    return [("a", LR.LidarConfig(N=10, Nc=5, R=3, aligned_bounds=True), np.array([0.0, 0.0, 0.1]), np.array([1.5, 0.8, 0.0])),
+            ("b", LR.LidarConfig(N=10, Nc=5, R=3, aligned_bounds=True), np.array([0.3, -0.2, 1.0]), np.array([-1.0, 0.5, 0.5])),
+            ("c", LR.LidarConfig(N=15, Nc=8, R=4, aligned_bounds=True), np.array([0.1, 0.0, 0.4]), np.array([1.8, 1.2, 0.3])),
+            ("d_script_bounds", LR.LidarConfig(N=12, Nc=6, R=4), np.array([0.2, 0.25, 0.3]), np.array([1.5, 1.0, 0.5]))]
+
+
+LIDAR_WORLD = [(1.2, 0.9, 0.25), (2.0, 2.2, 0.3)]      # the obstacle world of tests/test_oracle_lidar.py
+
+
+def make_lidar():
+    """scipy-SLSQP on oracle/lidar_ref.py's restatement of the LIDAR-state NLP (V4:78-151), cold start V4:184-196."""
+    from oracle import lidar_ref as LR
+    out = {}
+    for name, cfg, pose, xs in lidar_cases():
+        scan = LR.scan_of_world(pose, LIDAR_WORLD, cfg.R)
+        p = LR.make_p(cfg, pose, xs, scan); w0 = LR.cold_start(cfg, np.concatenate([pose, scan]))
+        lbx, ubx, _, _ = LR.bounds(cfg)
+
+        def run(wstart):
+            return minimize(lambda w: LR.objective(cfg, w, p), wstart, jac=lambda w: LR.grad_objective(cfg, w, p), bounds=Bounds(lbx, ubx),
+                            constraints=[{"type": "eq", "fun": lambda w: LR.constraints(cfg, w, p), "jac": lambda w: LR.jacobian(cfg, w, p)}],
+                            method="SLSQP", options={"ftol": 1e-14, "maxiter": 1000})
+        r = run(w0); r2 = run(r.x)
+        assert r.status in (0, 8) and r2.status in (0, 8), (name, r.message, r2.message)
+        k = LR.kkt_report(cfg, r2.x, p, tol_active=1e-4)
+        assert k["eq"] < 1e-9 and k["bnd"] < 1e-12, (name, k)
+        print("lidar", name, "f* = %.9f  (polish moved w by %.1e), kkt_report %s" % (r.fun, np.max(np.abs(r.x - r2.x)), k))
+        out.update({name + "_p": p, name + "_w0": w0, name + "_w": r.x, name + "_f": r.fun, name + "_w_pol": r2.x, name + "_f_pol": r2.fun,
+                    name + "_cfg": np.array([cfg.N, cfg.Nc, cfg.R, int(cfg.aligned_bounds)])})
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "slsqp_lidar.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "lidar" in sys.argv[1:]:
+        make_lidar()
+        sys.argv.remove("lidar")
+        if not sys.argv[1:]:
+            sys.exit(0)
     # usage: gen_golden.py [name ...]   (default: the four small sets; "six" takes ~8 min, "ten" ~25 min of one core)
     want = sys.argv[1:] or ["one", "two", "obs3", "three"]
     rng = np.random.Generator(np.random.PCG64(Hh.SEED0))

@@ -159,6 +159,58 @@ def test_lidar_edge_cases(built):
     assert L.nmpc_lidar_n_var(None) == -1
 
 
+def test_hip_lidar_matches_slsqp_golden(built):
+    """the HIP LIDAR solve DIRECTLY against tests/golden/slsqp_lidar.npz (scipy-SLSQP on the restated NLP — an independent solver, "not
+    CasADi/IPOPT"), tolerances of tests/test_oracle_lidar.py: objective 1e-6 relative, iterate 2e-4 (SLSQP's own accuracy); three triples with
+    aligned bounds and one with the bounds exactly as the script builds them (V4:161-176)."""
+    import torch
+    import nmpc_amd
+    from tests.test_oracle_lidar import _lidar_golden
+    n = 0
+    for name, cfg, p, w0, ws, fs in _lidar_golden():
+        lbx, ubx, _, _ = LR.bounds(cfg)
+        s = nmpc_amd.LidarSolver(_product(cfg, max_iter=500), lbx=lbx, ubx=ubx, max_batch=1)
+        r = _np(s.solve_batch(p[None], w0[None])); torch.cuda.synchronize()
+        assert r["status"][0] == 0 and r["kkt"][0] <= 1e-8, (name, r["status"], r["iters"], r["kkt"])
+        assert abs(r["f"][0] - fs) <= 1e-6 * max(1.0, abs(fs)), (name, r["f"][0], fs)
+        assert np.abs(r["x"][0] - ws).max() < 2e-4, (name, np.abs(r["x"][0] - ws).max())
+        k = LR.kkt_report(cfg, r["x"][0], p, tol_active=1e-4)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, (name, k)
+        print(f"lidar golden {name}: |f - f_slsqp| = {abs(r['f'][0] - fs):.2e}, max|w - w_slsqp| = {np.abs(r['x'][0] - ws).max():.2e}, iters {r['iters'][0]}")
+        n += 1
+    assert n == 4
+
+
+def test_lidar_two_long_horizon_handles_and_reproducible_objective(built):
+    """(a) The dynamic-LDS limit is an attribute of the kernel function, not of a handle: a handle that needs 86 KB (N = 450) must keep
+    solving after a second one with a smaller need (N = 300: 58 KB, below HIP's 64 KB default) has been created and used — solved in
+    creation order, then the first one again.  (b) sol['f'] of nmpc_lidar_eval_batch is summed in a fixed order: bit-identical between runs."""
+    import torch
+    import nmpc_amd
+    solvers = []
+    for N in (450, 300):
+        cfg = LR.LidarConfig(N=N, Nc=N // 2, R=3, aligned_bounds=True)
+        lbx, ubx, _, _ = LR.bounds(cfg)
+        P, W0 = _batch(cfg, 3, 40 + N)
+        solvers.append((cfg, nmpc_amd.LidarSolver(_product(cfg, max_iter=12), lbx=lbx, ubx=ubx, max_batch=3), P, W0))
+    for cfg, s, P, W0 in solvers + solvers[:1]:
+        r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()
+        ref = O.lidar_solve_batch(cfg, P, W0, max_iter=12)
+        assert (r["status"] == ref["status"]).all() and (r["iters"] == ref["iters"]).all(), (cfg.N, r["status"], ref["status"])
+        assert np.abs(r["x"] - ref["x"]).max() <= W_TOL
+    cfg, s, P, W0 = solvers[0]
+    f1, _ = s.eval_batch(P, W0); f2, _ = s.eval_batch(P, W0)
+    assert torch.equal(f1, f2)
+    cfg4 = LR.lidar_v4()
+    lbx, ubx, _, _ = LR.bounds(cfg4)
+    P4, W4 = _batch(cfg4, 64, 41)
+    s4 = nmpc_amd.LidarSolver(_product(cfg4), lbx=lbx, ubx=ubx, max_batch=64)
+    fs = [s4.eval_batch(P4, W4)[0] for _ in range(4)]
+    assert all(torch.equal(fs[0], f) for f in fs[1:])
+    fo = np.array([LR.objective(cfg4, w, p) for w, p in zip(W4, P4)])
+    assert np.abs(fs[0].cpu().numpy() - fo).max() <= 1e-12 * np.abs(fo).max()
+
+
 def test_lidar_full_size_batch_matches_oracle(built):
     """2048 V4 instances (N=100, Nc=50, the script's bounds as built) — the size class of the bench entry — against the oracle on every one."""
     import torch

@@ -303,7 +303,9 @@ def test_edge_cases(built):
         ref = O.solve_batch(O.make_config(cfg, max_iter=600), Pb, Wb)
         assert (rr["status"] == ref["status"]).all() and (rr["status"] == 0).all(), (name, rr["status"], ref["status"])
         dw_ = np.max(np.abs(rr["x"] - ref["x"]), axis=1)
-        assert (dw_ <= W_TOL).mean() >= (0.5 if name == "ten_N60" else 0.75), (name, dw_)      # ten_N60: 2 long, chaotic solves
+        print(f"{name}: same point {(dw_ <= W_TOL).sum()} of {B}, iterations hip {rr['iters']} oracle {ref['iters']}")
+        # measured (GPUTEST r3): every instance of every set in the oracle's basin; one instance of slack on the two sets of long solves
+        assert (dw_ <= W_TOL).sum() >= B - (1 if name in ("ten_N60", "six_N60") else 0), (name, dw_)
 
 
 def test_odometry_front_end(built):
@@ -328,6 +330,11 @@ def test_odometry_front_end(built):
     # the literal first callback: robot 1 of the two-robot script starts at (-0.7112, -0.7112, 0.785) (C2:213-216)
     pose = nmpc_amd.odometry_to_global([[0.1, 0.0, np.sin(0.2 / 2), np.cos(0.2 / 2)]], [R.C2_START[:3]]).cpu().numpy()[0]
     assert np.allclose(pose, [R.C2_START[0] + 0.1 * np.cos(0.785), R.C2_START[1] + 0.1 * np.sin(0.785), 0.985], atol=1e-15)
+
+
+# same-point counts of the 16 cold-retry fixtures (300-1500 iteration solves; the KKT point is what is asserted, see below), as measured
+# on the GPU box, less one instance of slack
+SAME_COLD_RETRY = {"3": 7, "2": 7}      # measured (GPUTEST r3): 8 of 16 on both kernels
 
 
 def test_cold_start_retry_rescues_stalls_and_cyclers(built):
@@ -357,7 +364,8 @@ def test_cold_start_retry_rescues_stalls_and_cyclers(built):
         assert (rc["status"] == 0).all() and (rc["kkt"] <= 1e-8).all(), (kernel, rc["status"], rc["iters"])
         # long, chaotic solves (300-700 iterations): the KKT point is what is compared, where the basin is the same
         same = np.max(np.abs(rc["x"] - refc["x"]), axis=1) <= W_TOL
-        assert same.mean() >= 0.4, (kernel, same)
+        print(f"cold-retry fixtures, kernel {kernel}: same point as the oracle {same.sum()} of {len(same)}; iterations hip {rc['iters']} oracle {refc['iters']}")
+        assert same.sum() >= SAME_COLD_RETRY[kernel], (kernel, same)
         for b in np.where(~same)[0][:3]:
             k = R.kkt_report(ccfg, rc["x"][b], z["p"][b], tol_active=1e-3)
             # feasibility is checked independently; stationarity is NOT asserted through the least-squares report here: these are the
@@ -376,9 +384,11 @@ def test_barrier_restart_rescues_composite_stalls(built):
     ocfg = _composite_cfg()
     ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), d["p"], d["w"])
     r = _np(_solver(ocfg, len(d["p"]), max_iter=2000).solve_batch(d["p"], d["w"]))
-    assert (ref["status"] == 0).mean() >= 0.75, ref["status"]
-    # these are the chaotic cases by construction (captured stalls): one of the twelve may end differently
-    assert (r["status"] == ref["status"]).mean() >= 0.9, (r["status"], ref["status"])
+    print(f"restart fixtures: oracle converged {(ref['status'] == 0).sum()} of {len(ref['status'])}, hip status equal {(r['status'] == ref['status']).sum()}")
+    # measured (GPUTEST r3): the oracle converges on 12 of 12, the HIP status equals the oracle's on 12 of 12.  These are the chaotic
+    # cases by construction (captured stalls): one of the twelve may end differently
+    assert (ref["status"] == 0).sum() >= len(ref["status"]) - 1, ref["status"]
+    assert (r["status"] == ref["status"]).sum() >= len(ref["status"]) - 1, (r["status"], ref["status"])
     both = (r["status"] == 0) & (ref["status"] == 0)
     assert (r["kkt"][both] <= 1e-8).all()
 
@@ -468,8 +478,8 @@ def test_every_script_preset_matches_oracle(built, name):
     ref = O.solve_batch(O.make_config(ocfg, max_iter=600), P, W0)
     assert (r["status"] == ref["status"]).all(), (r["status"], ref["status"])
     conv = r["status"] == 0
-    assert conv.mean() >= 0.87, r["status"]
+    assert conv.sum() >= B - 1, r["status"]          # measured (GPUTEST r3): all 8 converge, same basin 1.000, on every one of the 27 presets
     dw = np.max(np.abs(r["x"] - ref["x"]), axis=1)
     print(f"{name}: m={pcfg.m} N={pcfg.N} same-basin {(dw[conv] <= W_TOL).mean():.3f}, iters hip {r['iters'].mean():.1f} oracle {ref['iters'].mean():.1f}")
-    assert (dw[conv] <= W_TOL).mean() >= 0.87, dw
+    assert (dw[conv] <= W_TOL).sum() >= conv.sum() - 1, dw
     np.testing.assert_allclose(r["f"][conv & (dw <= W_TOL)], ref["f"][conv & (dw <= W_TOL)], rtol=F_RTOL, atol=1e-9)

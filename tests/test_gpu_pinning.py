@@ -67,7 +67,9 @@ def test_hip_matches_slsqp_golden(built, name):
     print(f"{name}: f agrees on {same.sum()}/{B}, max|dw| on those {dw[same].max() if same.any() else None}")
     big = name in ("six", "ten")      # 618 / 1030 variables: SLSQP stops at a stationarity of 2-4e-5 (w within ~3e-4), and on 2 of the 5 six-robot
     # instances (the literal antipodal swap among them) its cold start ends in a basin with a HIGHER objective than ours
-    assert same.mean() >= (0.5 if big else 0.8), (df, dw)
+    # measured (GPUTEST r3): objective agreement on one 6/6, two 5/6 (the sixth: another basin, re-checked below), obs3 4/4, three 3/3,
+    # six 3/5, ten 2/2 — the bounds below are those counts
+    assert same.sum() >= {"one": 6, "two": 5, "obs3": 4, "three": 3, "six": 3, "ten": 2}.get(name, int(np.ceil(0.8 * B))), (df, dw)
     assert (dw[same] < (5e-4 if big else 2e-4)).all(), dw
     for b in np.where(~same)[0]:
         k = R.kkt_report(cfg, r["x"][b], z["p"][b], tol_active=1e-3)
@@ -219,11 +221,12 @@ def test_longest_lds_horizon_in_every_launch_shape(built):
         assert np.abs(o - ref["x"]).max() <= 1e-6 or (ref["status"] != 0).any()
 
 
-@pytest.mark.parametrize("name,B", [("two", 4096), ("six", 4096), ("ten20", 512)])
+@pytest.mark.parametrize("name,B", [("two", 4096), ("six", 4096), ("ten20", 512), ("ten", 512), ("composite", 1024)])
 def test_full_size_bench_batches_match_oracle(built, name, B):
     """the parity tests ran batches of 8-128; this one runs the bench batches themselves (bench.make_batch: the north-star
     shapes N_robots in {2, 6, 10}, N=20, incl. the literal start/goal sets as instance 0) — 4096 instances for two and six robots, the
-    first 512 of the ten-robot batch (the CPU oracle needs ~0.1 s per ten-robot solve) — through the kernel nmpc_solve_batch picks at
+    first 512 of the ten-robot batch (the CPU oracle needs ~0.1 s per ten-robot solve), and the two per-GPU shards BASELINE
+    configs 4 / 5 name: ten robots at N=30, B=512 and the six-robot + eight-obstacle composite at B=1024, every instance — through the kernel nmpc_solve_batch picks at
     that size, against the oracle on every instance: status, iteration count, iterate (1e-6), objective."""
     import importlib.util
     import torch
@@ -254,7 +257,7 @@ def test_kernel_selection_by_team_size_and_batch(built):
             if kernel:
                 os.environ["NMPC_KERNEL"] = kernel
             s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg), max_batch=max_batch)
-            return [s.lib.nmpc_debug_kernel_choice(s._h, b) for b in B]
+            return [s.kernel_for_batch(b) for b in B]
         finally:
             os.environ.pop("NMPC_KERNEL", None)
             if old is not None:
@@ -279,7 +282,7 @@ def test_long_horizon_on_the_column_kernel(built):
     os.environ["NMPC_KERNEL"] = "3"
     try:
         s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=1500), max_batch=3)
-        assert s.lib.nmpc_debug_kernel_choice(s._h, 3) == 3
+        assert s.kernel_for_batch(3) == 3
     finally:
         os.environ.pop("NMPC_KERNEL", None)
     r = _np(s.solve_batch(P, W0)); torch.cuda.synchronize()

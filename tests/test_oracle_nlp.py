@@ -112,7 +112,7 @@ def test_c_eval_and_shift_match_numpy(name):
         X, U = R.unpack(c, W[b])
         np.testing.assert_array_equal(wn[b], R.pack(c, R.shift_states(c, X), R.shift(c.T, 0.0, U)[1]))
         np.testing.assert_allclose(x0n[b], R.plant_step(c, P[b, : c.nx], U[0]), atol=1e-15)
-    assert O.lib().nmpc_n_var(cc) == c.n_var and O.lib().nmpc_n_g(cc) == c.n_g
+    assert O.lib().nmpc_oracle_n_var(cc) == c.n_var and O.lib().nmpc_oracle_n_g(cc) == c.n_g
 
 
 def test_odometry_known_answers():

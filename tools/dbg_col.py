@@ -18,8 +18,6 @@ for kern in ("2", "3"):
     s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=its), max_batch=4)
     r = s.solve_batch(P, W0); torch.cuda.synchronize()
     L = s.lib
-    L.nmpc_debug_workspace.restype = C.c_int64
-    L.nmpc_debug_workspace.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     offs = (C.c_int64 * 5)()
     per = L.nmpc_debug_workspace(s._h, 0, None, 0, offs)
     buf = np.zeros(per)

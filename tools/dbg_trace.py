@@ -15,10 +15,8 @@ s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(ocfg, max_iter=mi), max_batch=B)
 r = s.solve_batch(P, W0); torch.cuda.synchronize()
 n = int(r["iters"][inst]) + 1
 out = np.zeros((n, 16))
-s.lib.nmpc_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 s.lib.nmpc_debug_trace(s._h, out.ctypes.data, n)
 out2 = np.zeros((n, 8))
-s.lib.nmpc_debug_trace2.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 s.lib.nmpc_debug_trace2(s._h, out2.ctypes.data, n)
 print("it      E0      e_d      e_c      e_h    szmax       mu    alpha      a_p      a_d    delta       nu     dphi      th0            f   s_d  mult")
 for i in range(n):

@@ -16,7 +16,8 @@ import nmpc_amd
 from oracle import nlp_ref as R
 from tests import helpers as Hh
 
-importlib.import_module("nmpc_amd.build").build(force=True)
+if not os.environ.get("NMPC_SO"):      # NMPC_SO: a profile build made beforehand (variants/)
+    importlib.import_module("nmpc_amd.build").build(force=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 REPS = int(os.environ.get("PHASE_REPS", "1"))
 name = sys.argv[2] if len(sys.argv) > 2 else "six"
@@ -25,7 +26,6 @@ cfg = Hh.to_product_cfg(ocfg, max_iter=2000)
 P, W0 = Hh.batch(ocfg, B, 2)
 s = nmpc_amd.NmpcSolver(cfg, max_batch=B)
 L = s.lib
-L.nmpc_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
 out = (C.c_int64 * 12)()
 r = s.solve_batch(P, W0); torch.cuda.synchronize()
 L.nmpc_debug_profile(s._h, out, 1)
