@@ -303,13 +303,12 @@ def main():
         nx = cfg.nx
         Pc, Wc = dP.clone(), dW0.clone()
         its, conv = [], []
-        prev_it = None      # dispatch-order hint of nmpc_solve_batch_ordered: previous period's iteration counts, longest first
+        # nmpc_step_batch: solve + shift + plant step + the next period's dispatch order (longest solves first), all on the device;
+        # the host only enqueues one call per period
+        order = torch.arange(B, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize(); t2 = time.perf_counter()
         for _ in range(args.closed_loop):
-            rr = solver.solve_batch(Pc, Wc, order=None if prev_it is None else torch.argsort(prev_it, descending=True))
-            prev_it = rr["iters"]
-            Wc, x0n = solver.shift_batch(Pc, rr["x"], plant=True)
-            Pc = torch.cat([x0n, Pc[:, nx:]], dim=1)
+            rr = solver.step_batch(Pc, Wc, order)
             its.append(rr["iters"]); conv.append(rr["status"])
         torch.cuda.synchronize(); t_cl = time.perf_counter() - t2
         its = torch.stack(its).double().cpu().numpy(); conv = torch.stack(conv).cpu().numpy()
@@ -317,7 +316,7 @@ def main():
                               "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
                               "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
                               "converged_frac": float((conv == 0).mean()),
-                              "note": "warm-started receding horizon: solve (dispatch order = previous period's iteration counts, longest first), then nmpc_shift_batch (plant step x0+T f(x0,u0) and guess shift) on device"}
+                              "note": "warm-started receding horizon, one nmpc_step_batch per period: solve (dispatch order = previous period's iteration counts, longest first), guess shift, plant step x0+T f(x0,u0) and the next order, all on the device"}
         torch.cuda.synchronize(); t3 = time.perf_counter()
         rh = solver.solve_batch(P, W0)
         xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()

@@ -166,6 +166,22 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
                          double *x0_next, void *stream);
 
 /*
+ * One control period of the receding-horizon loop for B swarms, entirely on the device and on one stream (C6:416-465 with the plant of
+ * AS/casadi_test.py:17-26, the stack SURVEY.md 3(C) describes): nmpc_solve_batch_ordered, then nmpc_shift_batch, then the dispatch order
+ * of the next period — no host round trip in between.
+ *   p      [B][2 n_x]  in: [x0; xs]; out: x0 replaced by the plant step x0 + T f(x0, u_0) of the solution (xs untouched: the caller
+ *                      changes goals between calls)                                                       (casadi_test.py:17-26,170)
+ *   w      [B][n_var]  in: the guess; out: the next guess, the shifted solution [X_1..X_N; X_{N-1}], [U_1..U_{N-1}; U_{N-1}]   (C6:450,465)
+ *   w_sol  [B][n_var]  out: sol['x'] of this period (its row U_0 is the control to apply, C6:444); must not alias w
+ *   obj, status, iters, kkt: as nmpc_solve_batch (may be NULL)
+ *   order  [B] int32   in: dispatch order of this period (a permutation of 0..B-1; anything else is detected and ignored);
+ *                      out: the instances sorted by this period's iteration counts, longest first — the hint for the next call.
+ *                      May be NULL (index order, no hint produced).  A caller's first call passes the identity.
+ */
+int32_t nmpc_step_batch(nmpc_handle_t *h, int32_t B, double *p, double *w, double *w_sol, double *obj, int32_t *status, int32_t *iters,
+                        double *kkt, int32_t *order, void *stream);
+
+/*
  * Odometry front-end of the scripts' callbacks (AS/centralized_two_robots_implementation.py:18-37): for n robots,
  *   odom [n][4] = (x_r, y_r, q_z, q_w) wheel-odometry pose in the robot's own start frame (q_w is carried but, as in the
  *                  reference, not used: yaw = 2 asin(q_z)),

@@ -23,7 +23,7 @@ LIDAR_EXPORTS = ["nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p", "nmpc_l
 DEBUG_EXPORTS = ["nmpc_debug_profile", "nmpc_debug_trace", "nmpc_debug_trace2", "nmpc_debug_workspace"]      # include/nmpc_debug.h
 QUERY_KERNEL_FOR_BATCH, QUERY_WORKSPACE_BYTES, QUERY_LDS_BYTES, QUERY_MAX_BATCH = 1, 2, 3, 4
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_create_opts", "nmpc_query", "nmpc_destroy",
-           "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
+           "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_step_batch", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
 
 
 class CConfig(C.Structure):
@@ -80,6 +80,7 @@ def load():
     L.nmpc_workspace_bytes.argtypes = [vp]; L.nmpc_workspace_bytes.restype = C.c_int64
     L.nmpc_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch.restype = i32
     L.nmpc_solve_batch_ordered.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_solve_batch_ordered.restype = i32
+    L.nmpc_step_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_step_batch.restype = i32
     L.nmpc_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_eval_batch.restype = i32
     L.nmpc_shift_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_shift_batch.restype = i32
     L.nmpc_odometry_batch.argtypes = [C.c_int64, vp, vp, vp, i32, vp]; L.nmpc_odometry_batch.restype = i32

@@ -21,6 +21,7 @@ struct nmpc_handle {
     int device;          // device the workspace lives on; made current for the duration of every call
     bool lat_ok;         // the element-per-lane kernel's latency shapes fit the LDS for this configuration
     int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
+    int32_t *it_buf;     // [max_batch] iteration counts of nmpc_step_batch when the caller passes iters == NULL
 };
 
 // makes the handle's device current for one call and restores the caller's on return
@@ -134,6 +135,7 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
     (void)hipMemset(h->prof, 0, (12 + 24 * 2048) * sizeof(long long));
     if (hipMalloc((void **)&h->ord_chk, sizeof(int32_t) * ((size_t)max_batch + 1)) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); free(h); return NMPC_E_NOMEM; }
     (void)hipMemset(h->ord_chk, 0, sizeof(int32_t) * ((size_t)max_batch + 1));
+    if (hipMalloc((void **)&h->it_buf, sizeof(int32_t) * (size_t)max_batch) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); (void)hipFree(h->ord_chk); free(h); return NMPC_E_NOMEM; }
     h->P.trace_inst = opts ? opts->trace_instance : -1;
     *out = h;
     return NMPC_OK;
@@ -145,6 +147,7 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
     if (h->ws) (void)hipFree(h->ws);
     if (h->prof) (void)hipFree(h->prof);
     if (h->ord_chk) (void)hipFree(h->ord_chk);
+    if (h->it_buf) (void)hipFree(h->it_buf);
     free(h);
     return NMPC_OK;
 }
@@ -196,6 +199,25 @@ int32_t nmpc_solve_batch_ordered(nmpc_handle_t *h, int32_t B, const double *p, c
     return solve_impl(h, B, p, w0, w_out, obj, status, iters, kkt, order, stream);
 }
 
+int32_t nmpc_step_batch(nmpc_handle_t *h, int32_t B, double *p, double *w, double *w_sol, double *obj, int32_t *status, int32_t *iters, double *kkt,
+                        int32_t *order, void *stream)
+{
+    if (!h || B < 0 || B > h->max_batch) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!p || !w || !w_sol || w == w_sol) return NMPC_E_ARG;
+    int32_t *it = iters ? iters : h->it_buf;
+    // 1. the solve, dispatched in the caller's order (checked to be a permutation; ignored otherwise)
+    int32_t rc = solve_impl(h, B, p, w, w_sol, obj, status, it, kkt, order, stream);
+    if (rc != NMPC_OK) return rc;
+    DeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
+    // 2. guess <- shift(solution) in place of the old guess; x0 <- x0 + T f(x0, u_0) in place of the x0 half of p
+    if (nmpc::launch_shift(h->P, h->cfg.m, B, p, w_sol, w, p, 2 * 3 * h->cfg.m, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
+    // 3. the next period's dispatch order: longest solves of this period first
+    if (order && nmpc::launch_order_by_iters(B, it, order, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
+    return NMPC_OK;
+}
+
 int32_t nmpc_eval_batch(nmpc_handle_t *h, int32_t B, const double *p, const double *w, double *f, double *g, void *stream)
 {
     if (!h || B < 0) return NMPC_E_ARG;
@@ -215,7 +237,7 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
     if (x0_next && !p_in) return NMPC_E_ARG;
     DeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, (hipStream_t)stream);
+    hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, 0, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

@@ -877,8 +877,8 @@ __global__ __launch_bounds__(256) void eval_kernel(const KParams P, int B, const
 
 // warm-start shift (C6:160-169,460-465) + optional plant step (casadi_test.py:17-26)
 template <int M_>
-__global__ __launch_bounds__(256) void shift_kernel(const KParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w_in,
-                                                     double *__restrict__ w_next, double *__restrict__ x0_next)
+__global__ __launch_bounds__(256) void shift_kernel(const KParams P, int B, const double *p_in, const double *__restrict__ w_in,
+                                                     double *__restrict__ w_next, double *x0_next, int x0_stride)
 {
     constexpr int NX = Geo<M_>::NX, NU = Geo<M_>::NU;
     const int N = P.N;
@@ -904,8 +904,11 @@ __global__ __launch_bounds__(256) void shift_kernel(const KParams P, int B, cons
         const double *u = w_in + (size_t)b * P.nvar + (size_t)(N + 1) * NX + 2 * i;
         double s, c;
         sincos(x0[2], &s, &c);
-        double *o = x0_next + (size_t)b * NX + 3 * i;
-        o[0] = x0[0] + P.T * u[0] * c; o[1] = x0[1] + P.T * u[0] * s; o[2] = x0[2] + P.T * u[1];
+        // x0_next may be the x0 part of p_in itself (nmpc_step_batch: stride 2 n_x): this thread reads its robot's three entries
+        // before it writes them, and no other thread touches them
+        const double n0 = x0[0] + P.T * u[0] * c, n1 = x0[1] + P.T * u[0] * s, n2 = x0[2] + P.T * u[1];
+        double *o = x0_next + (size_t)b * x0_stride + 3 * i;
+        o[0] = n0; o[1] = n1; o[2] = n2;
     }
 }
 
@@ -925,10 +928,10 @@ template <int M_> static hipError_t launch_eval_m(const KParams &P, int B, const
     hipLaunchKernelGGL((eval_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w, f, g);
     return hipGetLastError();
 }
-template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st)
+template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st)
 {
     long total = (long)B * P.nvar;
-    hipLaunchKernelGGL((shift_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w_in, w_next, x0n);
+    hipLaunchKernelGGL((shift_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w_in, w_next, x0n, x0_stride ? x0_stride : Geo<M_>::NX);
     return hipGetLastError();
 }
 
@@ -981,6 +984,40 @@ hipError_t launch_order_check(int B, const int32_t *order, int32_t *count, int32
     return hipGetLastError();
 }
 
+// Dispatch order of the next control period (nmpc_step_batch): the instances sorted by this period's iteration counts, longest first —
+// a counting sort over the keys min(iters, 2047) by ONE workgroup (histogram in LDS, exclusive scan over descending keys, scatter).
+// Instances with equal counts land in arbitrary relative order: the order only schedules, it never changes a result.
+__global__ __launch_bounds__(1024) void order_by_iters_kernel(int B, const int32_t *__restrict__ iters, int32_t *__restrict__ order)
+{
+    constexpr int NB = 2048;
+    __shared__ int hist[NB], offs[NB];
+    const int t = threadIdx.x;
+    for (int k = t; k < NB; k += 1024) hist[k] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) { int k = iters[i]; k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k); atomicAdd(&hist[NB - 1 - k], 1); }      // bin 0 = the longest solves
+    __syncthreads();
+    // exclusive scan of hist (2 bins per thread; Hillis-Steele over the per-thread sums)
+    const int a0 = hist[2 * t], a1 = hist[2 * t + 1];
+    offs[t] = a0 + a1;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? offs[t - d] : 0;
+        __syncthreads();
+        offs[t] += v;
+        __syncthreads();
+    }
+    const int base = offs[t] - (a0 + a1);
+    __syncthreads();
+    hist[2 * t] = base; hist[2 * t + 1] = base + a0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) { int k = iters[i]; k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k); order[atomicAdd(&hist[NB - 1 - k], 1)] = i; }
+}
+hipError_t launch_order_by_iters(int B, const int32_t *iters, int32_t *order, hipStream_t st)
+{
+    hipLaunchKernelGGL(order_by_iters_kernel, dim3(1), dim3(1024), 0, st, B, iters, order);
+    return hipGetLastError();
+}
+
 #define NMPC_DISPATCH(M, CALL)                                                                                                    \
     switch (M) {                                                                                                                  \
     case 1: return CALL(1);                                                                                                       \
@@ -1007,9 +1044,9 @@ hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const do
     NMPC_DISPATCH(m, C_)
 #undef C_
 }
-hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, hipStream_t st)
+hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st)
 {
-#define C_(M) launch_shift_m<M>(P, B, p, w_in, w_next, x0n, st)
+#define C_(M) launch_shift_m<M>(P, B, p, w_in, w_next, x0n, x0_stride, st)
     NMPC_DISPATCH(m, C_)
 #undef C_
 }

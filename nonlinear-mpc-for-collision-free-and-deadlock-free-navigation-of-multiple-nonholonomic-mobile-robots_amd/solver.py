@@ -162,6 +162,28 @@ class NmpcSolver:
             out["f"], out["g"] = f, g
         return out
 
+    def step_batch(self, p, w, order=None):
+        """One control period on the device (nmpc_step_batch): solve from the guess w, then IN PLACE w <- shifted solution and
+        p[:, :n_x] <- x0 + T f(x0, u_0); `order` [B] int32 device tensor (in: dispatch order of this period, out: the order for the
+        next one, sorted by this period's iteration counts, longest first) or None.  p and w must be contiguous float64 device
+        tensors owned by the caller (they are modified).  Returns sol['x'] of this period and the per-instance outputs."""
+        torch = self.torch
+        B = p.shape[0]
+        if not (torch.is_tensor(p) and torch.is_tensor(w) and p.is_cuda and w.is_cuda and p.dtype == torch.float64 and w.dtype == torch.float64
+                and p.is_contiguous() and w.is_contiguous() and p.shape == (B, self.n_p) and w.shape == (B, self.n_var)):
+            raise ValueError("step_batch works in place: p [B, n_p] and w [B, n_var] must be contiguous float64 device tensors")
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        if order is not None and not (torch.is_tensor(order) and order.is_cuda and order.dtype == torch.int32 and order.is_contiguous() and order.shape == (B,)):
+            raise ValueError("order must be a contiguous int32 device tensor of shape (B,)")
+        x = torch.empty((B, self.n_var), dtype=torch.float64, device=self.device)
+        obj = torch.empty(B, dtype=torch.float64, device=self.device); kkt = torch.empty(B, dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device); iters = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_step_batch(self._h, B, p.data_ptr(), w.data_ptr(), x.data_ptr(), obj.data_ptr(), status.data_ptr(), iters.data_ptr(),
+                                                kkt.data_ptr(), order.data_ptr() if order is not None else None, self._stream()), "nmpc_step_batch")
+        return dict(x=x, f=obj, status=status, iters=iters, kkt=kkt, order=order)
+
     def eval_batch(self, p, w):
         torch = self.torch
         p = self._dev(p, (-1, self.n_p)); B = p.shape[0]

@@ -246,6 +246,40 @@ def test_full_size_bench_batches_match_oracle(built, name, B):
     assert np.array_equal(r["x"][:, : ocfg.nx], P[:, : ocfg.nx])
 
 
+def test_step_batch_equals_the_separate_calls(built):
+    """nmpc_step_batch (solve + guess shift + plant step + next dispatch order, one call, in place) against nmpc_solve_batch_ordered,
+    nmpc_shift_batch and a host argsort over four control periods: bit-identical states, guesses and solutions; the order it returns is
+    a permutation sorted by the period's iteration counts, longest first.  (The separate calls are the ones the oracle checks in
+    tests/test_gpu_parity.py::test_closed_loop_steps_match_oracle.)"""
+    import torch
+    import nmpc_amd
+    ocfg = R.cfg_six(20)
+    B = 96
+    P, W0 = Hh.batch(ocfg, B, 2)
+    s = _solver(ocfg, B, max_iter=600)
+    nx = ocfg.nx
+    p1 = torch.as_tensor(P, device="cuda").clone(); w1 = torch.as_tensor(W0, device="cuda").clone()
+    order = torch.arange(B, dtype=torch.int32, device="cuda")
+    p2 = p1.clone(); w2 = w1.clone(); o2 = None
+    for period in range(4):
+        r1 = s.step_batch(p1, w1, order)
+        r2 = s.solve_batch(p2, w2, order=o2)
+        w2, x0n = s.shift_batch(p2, r2["x"], plant=True)
+        p2 = torch.cat([x0n, p2[:, nx:]], dim=1).contiguous()
+        o2 = torch.argsort(r2["iters"], descending=True, stable=True).to(torch.int32)
+        torch.cuda.synchronize()
+        assert torch.equal(r1["x"], r2["x"]) and torch.equal(r1["iters"], r2["iters"]) and torch.equal(r1["status"], r2["status"]), period
+        assert torch.equal(p1, p2) and torch.equal(w1, w2), period
+        o = order.cpu().numpy(); it = r1["iters"].cpu().numpy()
+        assert np.array_equal(np.sort(o), np.arange(B)) and (np.diff(it[o]) <= 0).all(), (period, it[o])
+    # order == NULL and iters == NULL are accepted by the C ABI
+    L = s.lib
+    xs_ = torch.empty_like(w1)
+    assert L.nmpc_step_batch(s._h, B, p1.data_ptr(), w1.data_ptr(), xs_.data_ptr(), None, None, None, None, None, None) == 0
+    assert L.nmpc_step_batch(s._h, B, p1.data_ptr(), w1.data_ptr(), w1.data_ptr(), None, None, None, None, None, None) == -1      # w_sol aliases w
+    torch.cuda.synchronize()
+
+
 def test_kernel_selection_by_team_size_and_batch(built):
     """nmpc_solve_batch picks the column-per-lane kernel (3) for throughput batches and the multi-wave element-per-lane shapes (2) where a
     batch cannot fill its slots (measured crossovers); NMPC_KERNEL pins one; horizons beyond the LDS fall back to 1."""
