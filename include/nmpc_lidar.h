@@ -65,6 +65,22 @@ int32_t nmpc_lidar_eval_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p
 /* warm-start shuffle of V4:258-270: U rows drop first / repeat last; X rows [X_1..X_N; X_{N-1}] */
 int32_t nmpc_lidar_shift_batch(nmpc_lidar_handle_t *h, int32_t B, const double *w_in, double *w_next, void *stream);
 
+/*
+ * The two inputs the script's loop gets from the robot, for a SIMULATED one (SURVEY.md 8(f) row 2 applied to V4:209-300); no handle, pure
+ * functions of their inputs like nmpc_odometry_batch:
+ *
+ * nmpc_lidar_scan_batch replaces callback_lidar (V4:29-36) by a synthetic LaserScan: scan [B][R], the range along ray m (angle
+ * theta + m 2 pi / R, V4:203-205) from pose [B][3] to the nearest of K circular obstacles world [B][K][3] = (ox, oy, radius), clipped to
+ * scan_max (the script turns inf into 3.5).
+ *
+ * nmpc_lidar_plant_batch replaces the odometry reading of the next period by the Euler model the NLP itself uses (V4:78-87; the offline
+ * plant of AS/casadi_test.py:17-26): pose_next [B][3] = pose + T f(pose, u_0), pose = p[:, 0:3] (row stride n_p = 6 + 2R), u_0 = the first
+ * control row of w_sol [B][n_var] (V4:247-256).  pose_next may be the pose part of p itself (pose_stride = n_p; 0 means 3).
+ */
+int32_t nmpc_lidar_scan_batch(int64_t B, int32_t R, int32_t K, const double *pose, const double *world, double scan_max, double *scan, void *stream);
+int32_t nmpc_lidar_plant_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w_sol, double *pose_next, int32_t pose_stride,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

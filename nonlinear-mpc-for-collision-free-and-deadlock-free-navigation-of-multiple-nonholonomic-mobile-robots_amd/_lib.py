@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Erro
 ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMPC_E_NOMEM"}
 
 LIDAR_EXPORTS = ["nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p", "nmpc_lidar_create", "nmpc_lidar_destroy", "nmpc_lidar_solve_batch",
-                 "nmpc_lidar_eval_batch", "nmpc_lidar_shift_batch"]
+                 "nmpc_lidar_eval_batch", "nmpc_lidar_shift_batch", "nmpc_lidar_scan_batch", "nmpc_lidar_plant_batch"]
 DEBUG_EXPORTS = ["nmpc_debug_profile", "nmpc_debug_trace", "nmpc_debug_trace2", "nmpc_debug_workspace"]      # include/nmpc_debug.h
 QUERY_KERNEL_FOR_BATCH, QUERY_WORKSPACE_BYTES, QUERY_LDS_BYTES, QUERY_MAX_BATCH = 1, 2, 3, 4
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_create_opts", "nmpc_query", "nmpc_destroy",
@@ -93,6 +93,8 @@ def load():
     L.nmpc_lidar_solve_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]; L.nmpc_lidar_solve_batch.restype = i32
     L.nmpc_lidar_eval_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp]; L.nmpc_lidar_eval_batch.restype = i32
     L.nmpc_lidar_shift_batch.argtypes = [vp, i32, vp, vp, vp]; L.nmpc_lidar_shift_batch.restype = i32
+    L.nmpc_lidar_scan_batch.argtypes = [C.c_int64, i32, i32, vp, vp, C.c_double, vp, vp]; L.nmpc_lidar_scan_batch.restype = i32
+    L.nmpc_lidar_plant_batch.argtypes = [vp, i32, vp, vp, vp, i32, vp]; L.nmpc_lidar_plant_batch.restype = i32
     _lib = L
     return L
 

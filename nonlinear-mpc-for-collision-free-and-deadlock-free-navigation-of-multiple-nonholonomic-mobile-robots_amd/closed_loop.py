@@ -146,3 +146,94 @@ def simulate_closed_loop(solver: NmpcSolver, x0, goals, max_steps: int, stop_tol
                          failed_solves=failed, total_solves=total,
                          mean_iters_by_step=torch.stack(its).cpu().numpy() if its else np.zeros(0),
                          states=torch.stack(states).cpu().numpy() if keep_states else None)
+
+
+@dataclass
+class LidarEpisodeResult:
+    steps: int                      # control periods executed
+    arrived: "np.ndarray"           # [B] bool: the last goal was reached (V4:284-291: goal_idx > ng)
+    arrival_step: "np.ndarray"      # [B] int: period at which that happened (-1: never)
+    goals_reached: "np.ndarray"     # [B] int: goals reached so far
+    min_clearance: "np.ndarray"     # [B] smallest distance from the robot's centre to an obstacle SURFACE over the episode (inf: no obstacle)
+    final_error: "np.ndarray"       # [B] ||pose - xs|| at the end
+    failed_solves: int              # solves that did not return status 0
+    total_solves: int
+    mean_iters_by_step: "np.ndarray"
+    poses: Optional["np.ndarray"] = None     # [steps+1, B, 3] when keep_poses
+
+
+def simulate_lidar_closed_loop(solver, pose0, goals, world, max_steps: int, arrive_tol: float = 0.2, scan_max: float = 3.5,
+                               keep_poses: bool = False) -> LidarEpisodeResult:
+    """The main loop of AllScripts/obs_avoid_static_first_scenario_v4.py (V4:209-300) for B simulated robots at once.
+
+    Per robot and control period (file:line of the reference):
+      scan <- LaserScan of the world around the robot            callback_lidar V4:29-36 (here: nmpc_lidar_scan_batch on a synthetic world)
+      p = [x0 pose; xs; scan; B0]                                V4:230-236
+      sol = solver(x0=guess, p=p, ...)                           V4:245
+      guess <- shift(sol)                                        V4:258-270 (row N-1 appended, controls drop first / repeat last)
+      robot moves with u[0]                                      V4:272-279 (here: the Euler model of the NLP itself, nmpc_lidar_plant_batch)
+      ne = ||Xr - xs|| < 0.2 -> next goal; past the last: arrived   V4:281-291 (goal_idx, ng)
+      x0[3:] = Scan ; x0[:3] = Xr                                V4:296-297
+    pose0 [B,3]; goals [B,G,3] (or [B,3]); world [B,K,3] circular obstacles (ox, oy, radius).  As in the script a non-converged solve's control is
+    applied as returned (counted in failed_solves); a robot that has arrived stays where it is and keeps solving its fixed point."""
+    torch = solver.torch
+    cfg = solver.cfg
+    dev = solver.device
+    pose = solver._dev(pose0, (-1, 3)).clone()
+    B = pose.shape[0]
+    g = torch.as_tensor(np.asarray(goals, dtype=np.float64) if not torch.is_tensor(goals) else goals, dtype=torch.float64, device=dev)
+    if g.dim() == 2:
+        g = g[:, None, :]
+    if g.shape[0] != B or g.shape[2] != 3:
+        raise ValueError(f"goals must be [B, 3] or [B, G, 3] with B={B}; got {tuple(g.shape)}")
+    G = g.shape[1]
+    wd = solver._dev(world, (B, -1, 3))
+    K = wd.shape[1]
+    ang = torch.arange(cfg.R, dtype=torch.float64, device=dev) * (2.0 * np.pi / cfg.R)      # B0 (V4:203-205)
+    gi = torch.zeros(B, dtype=torch.long, device=dev)
+    ar = torch.arange(B, device=dev)
+    arrived = torch.zeros(B, dtype=torch.bool, device=dev)
+    arrival = torch.full((B,), -1, dtype=torch.long, device=dev)
+    clear = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+
+    def track(pc):
+        nonlocal clear
+        if K:
+            clear = torch.minimum(clear, ((pc[:, None, :2] - wd[:, :, :2]).norm(dim=2) - wd[:, :, 2]).amin(dim=1))
+
+    scan = solver.scan_batch(pose, wd, scan_max)
+    # cold start of V4:184-196: X0 = repmat([pose; scan]), u0 = 0
+    w = torch.cat([torch.cat([pose, scan], dim=1).repeat(1, cfg.N + 1), torch.zeros((B, 2 * cfg.Nc), dtype=torch.float64, device=dev)], dim=1)
+    track(pose)
+    poses = [pose.clone()] if keep_poses else None
+    its = []
+    failed = total = steps = 0
+    for step in range(max_steps):
+        if bool(arrived.all()):
+            break
+        xs = g[ar, gi]
+        p = torch.cat([pose, xs, scan, ang[None, :].expand(B, -1)], dim=1).contiguous()
+        r = solver.solve_batch(p, w)
+        total += B
+        failed += int((r["status"] != 0).sum())
+        its.append(r["iters"].double().mean())
+        w = solver.shift_batch(r["x"])
+        pn = solver.plant_batch(p, r["x"])
+        pose = torch.where(arrived[:, None], pose, pn)
+        track(pose)
+        # V4:281-291: ne = ||Xr - xs|| < 0.2 -> goal_idx + 1; beyond ng the robot has arrived
+        hit = ((pose - xs).norm(dim=1) < arrive_tol) & ~arrived
+        last = gi == G - 1
+        newly = hit & last
+        arrival = torch.where(newly, torch.full_like(arrival, step + 1), arrival)
+        arrived |= newly
+        gi = torch.where(hit & ~last, gi + 1, gi)
+        scan = solver.scan_batch(pose, wd, scan_max)          # V4:296: x0[3:] = Scan
+        if keep_poses:
+            poses.append(pose.clone())
+        steps += 1
+    err = (pose - g[ar, gi]).norm(dim=1)
+    return LidarEpisodeResult(steps=steps, arrived=arrived.cpu().numpy(), arrival_step=arrival.cpu().numpy(), goals_reached=(gi + arrived.long()).cpu().numpy(),
+                              min_clearance=clear.cpu().numpy(), final_error=err.cpu().numpy(), failed_solves=failed, total_solves=total,
+                              mean_iters_by_step=torch.stack(its).cpu().numpy() if its else np.zeros(0),
+                              poses=torch.stack(poses).cpu().numpy() if keep_poses else None)

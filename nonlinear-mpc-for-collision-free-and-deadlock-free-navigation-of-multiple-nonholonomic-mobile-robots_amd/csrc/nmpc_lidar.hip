@@ -634,6 +634,39 @@ __global__ __launch_bounds__(256) void lidar_shift_kernel(const LParams P, int B
     w_next[gid] = v;
 }
 
+// synthetic LaserScan (callback_lidar, V4:29-36): one thread per (instance, ray); range to the nearest circular obstacle, clipped
+__global__ __launch_bounds__(256) void lidar_scan_kernel(long B, int R, int K, const double *__restrict__ pose, const double *__restrict__ world, double scan_max,
+                                                          double *__restrict__ scan)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * R) return;
+    const long b = gid / R;
+    const int m = (int)(gid - b * R);
+    const double x = pose[3 * b], y = pose[3 * b + 1], th = pose[3 * b + 2];
+    double s, c;
+    sincos(th + (double)m * (2.0 * 3.14159265358979323846) / (double)R, &s, &c);
+    double best = scan_max;
+    for (int o = 0; o < K; o++) {
+        const double *ob = world + ((size_t)b * K + o) * 3;
+        const double fx = ob[0] - x, fy = ob[1] - y, t = fx * c + fy * s, h2 = fx * fx + fy * fy - t * t, r2 = ob[2] * ob[2];
+        if (t > 0.0 && h2 < r2) best = fmin(best, t - sqrt(r2 - h2));
+    }
+    scan[gid] = best;
+}
+
+// plant step pose + T f(pose, u_0) (V4:78-87 as the robot; casadi_test.py:17-26)
+__global__ __launch_bounds__(256) void lidar_plant_kernel(const LParams P, int B, const double *p_in, const double *__restrict__ w_sol, double *pose_next, int stride)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double *x0 = p_in + (size_t)b * P.np, *u = w_sol + (size_t)b * P.nvar + (size_t)(P.N + 1) * P.ns;
+    double s, c;
+    sincos(x0[2], &s, &c);
+    const double n0 = x0[0] + P.T * u[0] * c, n1 = x0[1] + P.T * u[0] * s, n2 = x0[2] + P.T * u[1];      // read before written: pose_next may be p itself
+    double *o = pose_next + (size_t)b * stride;
+    o[0] = n0; o[1] = n1; o[2] = n2;
+}
+
 }  // namespace nmpc_lidar
 
 struct nmpc_lidar_handle {
@@ -754,6 +787,29 @@ int32_t nmpc_lidar_shift_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!dev.ok) return NMPC_E_HIP;
     const long total = (long)B * h->P.nvar;
     hipLaunchKernelGGL(nmpc_lidar::lidar_shift_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P, B, w_in, w_next);
+    return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_lidar_scan_batch(int64_t B, int32_t R, int32_t K, const double *pose, const double *world, double scan_max, double *scan, void *stream)
+{
+    if (B < 0 || R < 0 || R > NMPC_LIDAR_MAX_RAYS || K < 0 || !(scan_max > 0.0)) return NMPC_E_ARG;
+    if (B == 0 || R == 0) return NMPC_OK;
+    if (!pose || !scan || (K > 0 && !world)) return NMPC_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return NMPC_E_HIP;
+    const long total = (long)B * R;
+    hipLaunchKernelGGL(nmpc_lidar::lidar_scan_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)B, R, K, pose, world, scan_max, scan);
+    return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
+}
+
+int32_t nmpc_lidar_plant_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w_sol, double *pose_next, int32_t pose_stride, void *stream)
+{
+    if (!h || B < 0 || pose_stride < 0 || (pose_stride > 0 && pose_stride < 3)) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!p || !w_sol || !pose_next) return NMPC_E_ARG;
+    LidarDeviceScope dev(h->device);
+    if (!dev.ok) return NMPC_E_HIP;
+    hipLaunchKernelGGL(nmpc_lidar::lidar_plant_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->P, B, p, w_sol, pose_next, pose_stride ? pose_stride : 3);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

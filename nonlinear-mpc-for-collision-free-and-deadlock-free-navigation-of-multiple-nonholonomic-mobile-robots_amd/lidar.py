@@ -167,6 +167,27 @@ class LidarSolver:
             _lib.check(self.lib.nmpc_lidar_shift_batch(self._h, w.shape[0], w.data_ptr(), wn.data_ptr(), self._stream()), "nmpc_lidar_shift_batch")
         return wn
 
+    def scan_batch(self, pose, world, scan_max: float = 3.5):
+        """synthetic LaserScan of callback_lidar (V4:29-36) on the device: pose [B,3], world [B,K,3] = (ox, oy, radius) -> scan [B,R]."""
+        torch = self.torch
+        pose = self._dev(pose, (-1, 3)); B = pose.shape[0]
+        world = self._dev(world, (B, -1, 3)); K = world.shape[1]
+        scan = torch.empty((B, self.cfg.R), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_lidar_scan_batch(B, self.cfg.R, K, pose.data_ptr(), world.data_ptr() if K else None, float(scan_max), scan.data_ptr(), self._stream()),
+                       "nmpc_lidar_scan_batch")
+        return scan
+
+    def plant_batch(self, p, w_sol):
+        """pose + T f(pose, u_0) on the device (the robot of V4 replaced by the model of its own NLP): p [B,n_p], w_sol [B,n_var] -> [B,3]."""
+        torch = self.torch
+        p = self._dev(p, (-1, self.n_p)); B = p.shape[0]
+        w_sol = self._dev(w_sol, (B, self.n_var))
+        out = torch.empty((B, 3), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nmpc_lidar_plant_batch(self._h, B, p.data_ptr(), w_sol.data_ptr(), out.data_ptr(), 0, self._stream()), "nmpc_lidar_plant_batch")
+        return out
+
     def __call__(self, x0=None, p=None, lbx=None, ubx=None, lbg=None, ubg=None, **kw):
         """the reference's keyword call (V4:245); bounds must be the ones the solver was built with (they never change in the script)."""
         if kw:
