@@ -56,6 +56,11 @@
 typedef struct {
     int m, N, K, nx, nu, M, nxb, nh, thb;
     int trace;      /* NMPC_ORACLE_TRACE=1: one line per iteration on stderr (development aid) */
+    int ipopt;      /* NMPC_ORACLE_IPOPT_DEFAULTS=1: IPOPT-faithful variant for the basin-sensitivity estimate: mu_init = 0.1 unless the
+                       caller's differs from this solver's 0.5, filter line search (Waechter & Biegler alg. A: filter with margins, switching
+                       condition, Armijo on the barrier function) instead of the l1 merit function, dual step length from its own
+                       fraction-to-the-boundary rule (no cap by the primal step), no cold-start retry.  Not reproduced: second-order correction,
+                       the restoration phase (the barrier restart stands in), IPOPT's NLP scaling and linear solver.  Never the shipped algorithm. */
     int max_restarts;   /* barrier restarts after a stall: 3 (as the HIP path); NMPC_ORACLE_MAX_RESTARTS overrides (fixture generation) */
     int o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;
     double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin;
@@ -104,6 +109,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     w->trace = getenv("NMPC_ORACLE_TRACE") != NULL;
     w->max_restarts = getenv("NMPC_ORACLE_MAX_RESTARTS") ? atoi(getenv("NMPC_ORACLE_MAX_RESTARTS")) : 3;
     w->pc = getenv("NMPC_ORACLE_PC") ? atoi(getenv("NMPC_ORACLE_PC")) : 0;
+    w->ipopt = getenv("NMPC_ORACLE_IPOPT_DEFAULTS") ? atoi(getenv("NMPC_ORACLE_IPOPT_DEFAULTS")) : 0;
     w->nxb = m * (w->thb ? 3 : 2);
     w->nh = 2 * w->nu + 2 * w->nxb + w->M + m * w->K;
     w->o_ul = 0; w->o_uu = w->nu; w->o_xl = 2 * w->nu; w->o_xu = w->o_xl + w->nxb;
@@ -111,6 +117,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     w->T = c->T; w->dmin2 = c->dmin * c->dmin; w->vmax = c->v_max; w->wmax = c->w_max;
     w->xymax = c->xy_max; w->thmax = c->th_max; w->robdim = c->rob_dim; w->margin = c->margin;
     w->tol = c->tol; w->mu_init = c->mu_init; w->max_iter = c->max_iter;
+    if (w->ipopt && c->mu_init == 0.5) w->mu_init = 0.1;      /* IPOPT's default where the caller did not choose */
     memcpy(w->obs, c->obs, sizeof(w->obs));
     for (int i = 0; i < m; i++) {
         for (int d = 0; d < 3; d++) w->qd[3 * i + d] = c->q[d];
@@ -341,13 +348,17 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     double mh0 = 0.0, mh1 = 0.0, mh2 = 0.0, mh_mu = -1.0, mh_nu = -1.0;   /* merit values of the last three iterates (same mu, nu) */
     int mcount = 0;
     int it = 0, need_shift = 0, n_tiny = 0, n_restart = 0;
+    /* filter of the IPOPT-faithful variant (w->ipopt): pairs (theta, phi) no trial point may be dominated by; reset with every barrier problem */
+    enum { FMAX = 512 };
+    double flt_th[FMAX], flt_ph[FMAX], flt_mu = -1.0, th_init = -1.0;
+    int nflt = 0;
     /* Cold-start retry: a solve that stalls after its barrier restarts, fails numerically, or is still iterating after
        NMPC_COLD_RETRY_ITERS iterations is restarted from the reference's own cold start X_k = x0, U = 0 (C6:398-400) instead
        of the caller's guess — at most twice, the second time with mu = 10 mu_init (of the 5 composite solves the first retry does
        not rescue, all converge from the cold start with another initial barrier parameter: 0.1, 2 and 5 were tried).  This is the restoration of last resort: a warm start shifted from the previous period can sit in a
        region from which the iteration converges to an infeasible stationary point or cycles; from the cold start all captured
        failures of the six-robot + eight-obstacle closed loop converge (13 of 10,240 solves, tests/golden/cold_retry_cases.npz). */
-    int n_cold = getenv("NMPC_ORACLE_NO_COLD_RETRY") ? NMPC_COLD_RETRIES : 0;      /* (fixture generation: capture the failures the retry rescues) */
+    int n_cold = (getenv("NMPC_ORACLE_NO_COLD_RETRY") || w->ipopt) ? NMPC_COLD_RETRIES : 0;      /* (fixture generation: capture the failures the retry rescues) */
     int it_base = 0;      /* iteration at which the current attempt started (watchdog reference) */
 #define COLD_RETRY()                                                                                                              \
     do {                                                                                                                          \
@@ -701,6 +712,34 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                 t = w->dZ; w->dZ = w->dZc; w->dZc = t; t = w->lamn; w->lamn = w->lamnc; w->lamnc = t;
             }
         }
+        if (w->ipopt) {
+            /* Waechter & Biegler (2006) algorithm A, steps A-5.*: filter line search on (theta, phi) = (l1 infeasibility, barrier function).
+               gamma_theta = 1e-5, gamma_phi = 1e-8, delta = 1, s_theta = 1.1, s_phi = 2.3, eta_phi = 1e-4, theta_min = 1e-4 max(1, theta_0),
+               theta_max = 1e4 max(1, theta_0) (IPOPT's defaults) */
+            const double g_th = 1e-5, g_ph = 1e-8, s_th = 1.1, s_ph = 2.3, eta = 1e-4;
+            if (th_init < 0.0) th_init = th0;
+            const double th_min = 1e-4 * fmax(1.0, th_init), th_max = 1e4 * fmax(1.0, th_init);
+            if (flt_mu != mu) { nflt = 0; flt_mu = mu; }
+            int accepted = 0, armijo_case = 0;
+            for (int ls = 0; ls < 30; ls++) {
+                for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
+                for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
+                for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + alpha * w->dS[i];
+                ft = eval_point(w, xs, w->Xt, w->Ut, w->snt, w->cst, w->Ct, w->Ht);
+                double tht, phit = barrier_and_infeas(w, ft, w->Ct, w->Ht, w->St, mu, &tht);
+                int ok_f = (tht <= th_max) && (phit == phit);
+                for (int j = 0; j < nflt && ok_f; j++) if (tht >= flt_th[j] && phit >= flt_ph[j]) ok_f = 0;
+                if (ok_f) {
+                    const int sw = dphi < 0.0 && alpha * pow(-dphi, s_ph) > pow(th0, s_th);       /* switching condition (19) */
+                    if (th0 <= th_min && sw) { if (phit <= phi0 + eta * alpha * dphi + 1e-13 * fabs(phi0)) { accepted = 1; armijo_case = 1; } }
+                    else if (tht <= (1.0 - g_th) * th0 || phit <= phi0 - g_ph * th0) accepted = 1;
+                }
+                if (accepted) break;
+                if (ls < 29) alpha *= 0.5;
+            }
+            /* A-7: augment the filter unless the step was an Armijo step on the barrier function */
+            if (!armijo_case && nflt < FMAX) { flt_th[nflt] = (1.0 - g_th) * th0; flt_ph[nflt] = phi0 - g_ph * th0; nflt++; }
+        } else
         for (int ls = 0; ls < 30 && !pc_taken; ls++) {
             for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
             for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
@@ -714,7 +753,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                               it, kkt, mu, f, th0, alpha, a_p, a_d, delta_last, nu_pen, dphi, ntry);
         /* the duals never step further than the primal variables actually moved: a dual step taken
            without its primal counterpart (line search cut alpha) blows up the dual infeasibility of rows with tiny slacks */
-        a_d = fmin(a_d, alpha);
+        if (!w->ipopt) a_d = fmin(a_d, alpha);
         /* stall: the search direction is blocked (slacks pinned at zero with the infeasibility not decreasing) — the iterate
            is converging to an infeasible stationary point; IPOPT would enter restoration here, this solver reports it */
         n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
