@@ -29,7 +29,8 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
     for r in rows:
         w.writerow([r[0], r[1], r[2], "%.1f" % r[3], "%.4f" % (100.0 * r[2] / tot), r[4], r[5]])
 solve = [r for r in rows if KERNEL in r[0]][0]
-sym = c.execute("select kernel_name, group_segment_size, private_segment_size, sgpr_count, arch_vgpr_count, accum_vgpr_count from kernel_symbols where kernel_name like ?", ("%" + KERNEL + "%",)).fetchall()
+# the symbol of the kernel that was actually dispatched (the library holds one instantiation per team size)
+sym = c.execute("select kernel_name, group_segment_size, private_segment_size, sgpr_count, arch_vgpr_count, accum_vgpr_count from kernel_symbols where display_name = ?", (solve[0],)).fetchall()
 disp = c.execute("select grid_x, workgroup_x, lds_size, scratch_size from kernels where name like ? limit 1", ("%" + KERNEL + "%",)).fetchone()
 
 
@@ -51,7 +52,9 @@ traffic = {
     "correction": "KB units; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE as read; separate --pmc passes",
     "workload": json.load(open(os.path.join(src, "bench_fetch.json")))["config"],
     "dispatch": {"grid_x": disp[0], "workgroup_x": disp[1], "lds_bytes": disp[2], "scratch_bytes_per_lane": disp[3]},
-    "registers": [{"kernel": s[0][:60], "lds_static": s[1], "scratch": s[2], "sgpr": s[3], "vgpr": s[4], "agpr": s[5]} for s in sym],
+    "registers": [{"kernel": s[0][:60], "lds_static": s[1], "scratch_bytes_per_lane": s[2], "sgpr": s[3], "arch_vgpr_as_rocprofv3_reports": s[4], "accum_vgpr": s[5],
+                   "note": "rocprofv3's arch_vgpr_count is half of the unified 512-entry file's allocation on gfx950 (a kernel compiled to 244-256 VGPRs shows 128); "
+                           "the code object's own .vgpr_count (hipcc -S) is the figure DESIGN.md quotes"} for s in sym],
 }
 bj = json.load(open(os.path.join(src, "bench_fetch.json")))
 import re as _re
