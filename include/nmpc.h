@@ -103,14 +103,15 @@ int32_t nmpc_destroy(nmpc_handle_t *h);
  */
 typedef struct nmpc_options {
     int32_t kernel;         /* 0: the library picks the solve kernel per batch size (default).  1 HBM-resident, 2 element-per-lane,
-                               3 column-per-lane: that kernel for every batch size it can run (tests and A/B measurements)          */
+                               3 column-per-lane in its throughput shape (one wavefront per instance), 4 column-per-lane in its latency
+                               shape (two wavefronts per instance): that kernel for every batch size it can run (tests, A/B measurements) */
     int32_t trace_instance; /* -DNMPC_PROFILE builds: instance whose per-iteration trace is recorded (include/nmpc_debug.h); -1 none */
 } nmpc_options_t;
 int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out);
 
 /*
  * Facts about a handle.  Returns the value, or a negative NMPC_E_* code.
- *   NMPC_QUERY_KERNEL_FOR_BATCH  arg = B: the solve kernel nmpc_solve_batch launches for a batch of B (1 / 2 / 3 as in nmpc_options_t)
+ *   NMPC_QUERY_KERNEL_FOR_BATCH  arg = B: the solve kernel nmpc_solve_batch launches for a batch of B (1 / 2 / 3 / 4 as in nmpc_options_t)
  *   NMPC_QUERY_WORKSPACE_BYTES   device workspace held by the handle (same as nmpc_workspace_bytes)
  *   NMPC_QUERY_LDS_BYTES         arg = B: dynamic LDS per swarm instance of that kernel (0 for the HBM-resident kernel's fixed carve-up)
  *   NMPC_QUERY_MAX_BATCH         the max_batch the handle was created for

@@ -16,10 +16,13 @@ struct nmpc_handle {
     int32_t max_batch;
     double *ws;          // device workspace: max_batch * stride doubles
     int64_t ws_bytes;
-    int kernel;          // 3 = column-per-lane LDS-resident kernel (default), 2 = element-per-lane LDS-resident kernel, 1 = HBM-resident workgroup kernel
+    int kernel;          // 3 = column-per-lane LDS-resident kernel (default), 2 = element-per-lane LDS-resident kernel, 1 = HBM-resident workgroup kernel, 4 = 3 pinned to its latency shape
     long long *prof;     // device counters of the NMPC_PROFILE build (12 x int64), else unused
     int device;          // device the workspace lives on; made current for the duration of every call
     bool lat_ok;         // the element-per-lane kernel's latency shapes fit the LDS for this configuration
+    int col_lat;         // column kernel shape pin: 1 latency, -1 throughput, 0 by batch size
+    bool col_lat_ok;     // the column kernel's latency shape (two wavefronts per instance, duals in LDS up to six robots) fits the LDS
+    int32_t lat_slots;   // instances of that shape the device holds at once
     int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
     int32_t *it_buf;     // [max_batch] iteration counts of nmpc_step_batch when the caller passes iters == NULL
 };
@@ -96,7 +99,7 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
 int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out)
 {
     if (!cfg || !out || max_batch < 1) return NMPC_E_ARG;
-    if (opts && (opts->kernel < 0 || opts->kernel > 3)) return NMPC_E_ARG;
+    if (opts && (opts->kernel < 0 || opts->kernel > 4)) return NMPC_E_ARG;
     if (cfg->N < 2 || cfg->N > 4096 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
     if (!(cfg->T > 0.0) || !(cfg->v_max > 0.0) || !(cfg->w_max > 0.0) || !(cfg->xy_max > 0.0) || !(cfg->th_max > 0.0)) return NMPC_E_ARG;
     if (!(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0) return NMPC_E_ARG;
@@ -116,11 +119,21 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
     const int pin = opts ? opts->kernel : 0;      // 0: chosen per batch size (kernel_for_batch)
-    h->kernel = pin ? pin : 3;
+    h->kernel = pin ? (pin == 4 ? 3 : pin) : 3;
+    h->col_lat = pin == 4 ? 1 : (pin == 3 ? -1 : 0);      // 1: latency shape always, -1: throughput shape always, 0: by batch size
     // horizons whose iterate does not fit the 160 KB of LDS of a CU run on the HBM-resident kernel (same algorithm, slower)
-    if (h->kernel == 3 && nmpc::col_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 2;
+    if (h->kernel == 3 && nmpc::col_kernel_bytes(h->P, cfg->m, 0) > (size_t)160 * 1024) h->kernel = 2;
+    {
+        const size_t lb = nmpc::col_kernel_bytes(h->P, cfg->m, 1);
+        h->col_lat_ok = lb > 0 && lb <= (size_t)160 * 1024;
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const int by_regs = cfg->m <= 6 ? 4 : 2, by_lds = h->col_lat_ok ? (int)((size_t)160 * 1024 / lb) : 0;
+        h->lat_slots = cus * (by_lds < by_regs ? by_lds : by_regs);
+    }
     if (h->kernel == 2 && nmpc::lds_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 1;
-    h->lat_ok = pin != 3 && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
+    h->lat_ok = pin != 3 && pin != 4 && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
     nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
     {   // slack / dual arrays of the column kernel: pair, obstacle, control-bound (slacks + duals) and state-bound (duals) rows
         const int64_t N = cfg->N, N1 = N + 1, m = cfg->m, NPd = m * (m - 1) / 2, MK = m * cfg->n_obs, NU = 2 * m, NXB = h->P.nxb;
@@ -158,7 +171,18 @@ int64_t nmpc_workspace_bytes(const nmpc_handle_t *h) { return h ? h->ws_bytes : 
 static int kernel_for_batch(const nmpc_handle_t *h, int32_t B)
 {
     int kern = h->kernel;
-    if (kern == 3 && h->lat_ok && ((h->cfg.m >= 8 && B <= 256) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 512))) kern = 2;
+    if (kern == 3 && h->col_lat == 1) return h->col_lat_ok ? 4 : 3;      // pinned to the column kernel's latency shape
+    if (kern == 3 && h->col_lat == 0 && h->col_lat_ok && h->cfg.m >= 4) {
+        // The column kernel's latency shape (two wavefronts per instance) where the launch lasts as long as its longest solve.  It holds
+        // lat_slots instances at once (4 per CU up to six robots: 256 VGPRs per wave; 2 per CU beyond; fewer when the LDS says so: the
+        // composite's 63 KB with its duals make it 2 per CU = 512).
+        // Measured, solves/s (throughput | latency shape): six robots B=512 34.6 k | 42.4 k, 1024 67 k | 83 k, 2048 122 k | 151 k, 4096 188 k | 174 k;
+        // composite 512 13.2 k | 18.6 k, 1024 25.4 k | 28.7 k, 2048 43.4 k | 41.2 k; ten robots N=20 512 13.5 k | 16.0 k, 1024 26.5 k | 31.5 k,
+        // 2048 49.5 k | 41.6 k; N=30 512 5.9 k | 6.9 k, 1024 11.2 k | 11.2 k.  Up to three robots a phase has no more than 64 items: nothing
+        // for a second wave to do (two robots 1024: 457 k | 462 k).
+        if (B <= 2 * h->lat_slots) return 4;      // every measured crossover lies between two and four rounds of instances
+    }
+    if (kern == 3 && h->col_lat == 0 && !h->col_lat_ok && h->lat_ok && ((h->cfg.m >= 8 && B <= 256) || (h->cfg.m >= 5 && h->cfg.m <= 6 && B <= 512))) kern = 2;
     return kern;
 }
 
@@ -183,7 +207,7 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     const int kern = kernel_for_batch(h, B);
     hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                    : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)
-                                 : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream);
+                                 : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream, kern == 4);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
@@ -260,7 +284,7 @@ int64_t nmpc_query(const nmpc_handle_t *h, int32_t what, int64_t arg)
     case NMPC_QUERY_LDS_BYTES: {
         if (arg < 0 || arg > h->max_batch) return NMPC_E_ARG;
         const int k = kernel_for_batch(h, (int32_t)arg);
-        return k == 3 ? (int64_t)nmpc::col_kernel_bytes(h->P, h->cfg.m) : (k == 2 ? (int64_t)nmpc::lds_kernel_bytes(h->P, h->cfg.m) : 0);
+        return (k == 3 || k == 4) ? (int64_t)nmpc::col_kernel_bytes(h->P, h->cfg.m, k == 4) : (k == 2 ? (int64_t)nmpc::lds_kernel_bytes(h->P, h->cfg.m) : 0);
     }
     case NMPC_QUERY_MAX_BATCH: return h->max_batch;
     default: return NMPC_E_ARG;

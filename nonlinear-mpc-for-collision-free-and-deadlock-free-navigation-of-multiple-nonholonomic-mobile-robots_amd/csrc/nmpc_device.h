@@ -35,8 +35,8 @@ hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, con
                             int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
 size_t lds_kernel_bytes(const KParams &P, int m);
 hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
-                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st);
-size_t col_kernel_bytes(const KParams &P, int m);
+                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape);      // shape: 0 throughput, 1 latency (two wavefronts per instance)
+size_t col_kernel_bytes(const KParams &P, int m, int shape);
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
 hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st);      // x0_stride: doubles between the x0_next rows (0 = n_x)

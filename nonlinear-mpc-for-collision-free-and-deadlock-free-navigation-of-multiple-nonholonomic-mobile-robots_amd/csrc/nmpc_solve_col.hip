@@ -36,13 +36,16 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #define NMPC_COL_GB ((M_ == 6) ? (NX + 2) / 2 : NX + 1)      // rows per batch of the G = P [B A] gathers.  Measured: six robots in two batches +2.7 % (batch of 3 -> 166 k, 5 -> 171 k, 10 -> 172 k, 13 -> 173 k, all 19 rows at once -> 165 k solves/s); two robots +-0, ten robots -2.5 %: one batch there
 #endif
 #ifndef NMPC_FW_PD
-#define NMPC_FW_PD 2         // stages the forward sweep requests its rows ahead
+#define NMPC_FW_PD 1         // stages the forward sweep requests its rows ahead (measured on the row-paired kernel: 1 -> 198.5 k, 2 -> 194 k, 3 -> 191 k, 4 -> 176 k solves/s; B=16384: 299 k vs 290 k — the rows come from L2, the ring costs registers)
 #endif
 #ifndef NMPC_FW_FAKE
 #define NMPC_FW_FAKE 0       // development: 1 = the forward sweep re-reads stage 0's rows (wrong results; separates compute from memory time)
 #endif
 #ifndef NMPC_COL_DPP
 #define NMPC_COL_DPP 1
+#endif
+#ifndef NMPC_COL_WAVES_SMALL
+#define NMPC_COL_WAVES_SMALL 2      // resident waves per SIMD the register budget of up to three robots is set for (3: 168 VGPRs; measured below)
 #endif
 #ifndef NMPC_COL_RP
 #define NMPC_COL_RP 1        // row-paired backward sweep for two to six robots (see the sweep); 0 keeps one row per register (A/B)
@@ -80,14 +83,19 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
 }
 
-template <int M_, int THB, int DL>
-__global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
+// TPBK: threads per instance.  64 = the throughput shape (one wavefront per instance).  128 = the LATENCY shape: a second wavefront shares
+// the stage-parallel phases (evaluation, optimality error, stage packs, step lengths, multipliers, merit function, update — 41 % of a lone
+// wave's iteration for six robots) and waits at a barrier while wave 0 runs the two sweeps; for batches whose launch is as long as their
+// longest solve.
+template <int M_, int THB, int DL, int TPBK = 64>
+__global__ __launch_bounds__(TPBK, (M_ <= 3 ? NMPC_COL_WAVES_SMALL : (M_ <= 6 ? 2 : 1))) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                         double *__restrict__ w_out, double *__restrict__ obj_out,
                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
                                                         double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
 {
     using G = G2<M_, THB>;
-    constexpr int TPB = 64;
+    constexpr int TPB = TPBK;
+    static_assert(TPBK == 64 || TPBK == 128, "one or two wavefronts per instance");
     constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
     static_assert(NZ <= 64, "one lane per column of the augmented matrix");
@@ -572,6 +580,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
         bool ok;
         for (;;) {
             ok = true;
+            if (TPBK == 64 || tid < 64) {          // the sweep is wave 0's (the second wave of the latency shape waits at the barrier below)
+            constexpr int TPB = 64;
             if constexpr (RP) {
             // ==== row-paired sweep (up to six robots): BOTH 32-lane halves of the wave hold every column, and the rows are split between
             // them by robot parity — the lower half keeps the rows of robots 0, 2, 4 (and the right-hand side), the upper half those of
@@ -667,9 +677,16 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 }
                 // ---- 2. G = P [B A] (and the same combination of the right-hand side): own column + two gathered columns
                 {
-                    double tA[NS + 1], tB[NS + 1];
-                    static_for<0, NS + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q] = lane_gather(srcA2, m[NC + q]); tB[q] = lane_gather(srcB2, m[NC + q]); });
-                    static_for<0, NS + 1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NC + q] = fma(kB, tB[q], fma(kA, tA[q], kO * m[NC + q])); });
+#ifndef NMPC_RP_GB
+#define NMPC_RP_GB (NS + 1)      // rows per batch of the gathers (all of a batch issued before its first use)
+#endif
+                    constexpr int GB2 = NMPC_RP_GB;
+                    static_for<0, (NS + 1 + GB2 - 1) / GB2>([&](auto bc) {
+                        constexpr int q0 = decltype(bc)::value * GB2, q1 = (q0 + GB2 < NS + 1) ? q0 + GB2 : NS + 1;
+                        double tA[GB2], tB[GB2];
+                        static_for<q0, q1>([&](auto rc) { constexpr int q = decltype(rc)::value; tA[q - q0] = lane_gather(srcA2, m[NC + q]); tB[q - q0] = lane_gather(srcB2, m[NC + q]); });
+                        static_for<q0, q1>([&](auto rc) { constexpr int q = decltype(rc)::value; m[NC + q] = fma(kB, tB[q - q0], fma(kA, tA[q - q0], kO * m[NC + q])); });
+                    });
                 }
                 PROF_T(9);
                 // ---- 3. [B A]^T G: row operations inside each half (a robot's rows live in one half), coefficients per half
@@ -908,6 +925,13 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                 // what is left in rows NU.. of the state lanes is [P_k | p_k]
             }
             }
+            }
+            if constexpr (TPBK > 64) {      // wave 0's verdict on the factorisation reaches the other wave through LDS
+                if (tid == 0) RED[7] = ok ? 1.0 : 0.0;
+                __syncthreads();
+                ok = __builtin_amdgcn_readfirstlane(RED[7] != 0.0 ? 1 : 0) != 0;
+                __syncthreads();
+            }
             if (ok) break;
             ntry++;
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
@@ -930,6 +954,8 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
         //                          adds bcast(du_c) * row[c] to every later row's accumulator — one multiply-add per control
         //                          (controls 16.. of the larger teams sit in the second row of 16 B lanes: v_readlane broadcast)
         // Each T / B lane loads ITS row straight from HBM/L2 into registers (dwordx4, PD stages ahead).
+        if (TPBK == 64 || tid < 64) {              // wave 0's as well
+        constexpr int TPB = 64;
         if constexpr (NU <= 32 && NX <= 32) {
             constexpr int LDC = G::LDC, CT = (NX + 3) & ~1, CH = CT / 2, PD = NMPC_FW_PD;
             static_assert(NU + CT <= LDC && NU <= CT, "row chunks of the forward sweep");
@@ -1004,7 +1030,6 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                     }
                 });
             }
-            __syncthreads();
         } else {
             // larger teams: the stage factors stream back through a register ring filled PD stages ahead by all lanes (coalesced),
             // then through an LDS staging buffer (the pack area, free here); the control lanes form t and substitute back with
@@ -1064,8 +1089,9 @@ __global__ __launch_bounds__(64, (M_ <= 6 ? 2 : 1)) void solve_col_kernel(const 
                     }
                 }
             }
-            __syncthreads();
         }
+        }
+        __syncthreads();
         PROF_T(4);
 
         // ============ D. fraction to the boundary (IPOPT eq. 15) over all inequality slots (ds, dz recomputed)
@@ -1347,51 +1373,56 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool du
 template <int M_, int THB> static bool col_duals_in_lds(const KParams &P) { return M_ <= NMPC_COL_DL_MAXM && col_lds_bytes<M_, THB>(P, true) <= NMPC_COL_DL_BYTES; }
 
 template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
-                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+                                                        int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
 {
     constexpr int DLmax = (M_ <= NMPC_COL_DL_MAXM) ? 1 : 0;
-    const bool dl = DLmax && col_duals_in_lds<M_, THB>(P);
+    // latency shape (two wavefronts per instance): slacks and duals in LDS up to six robots — occupancy is not what a launch that lasts as
+    // long as its longest solve is short of — and in the workspace for eight and ten
+    constexpr int DLlat = (M_ <= 6) ? 1 : 0;
+    const bool lat = shape == 1;
+    const bool dl = lat ? (DLlat != 0) : (DLmax && col_duals_in_lds<M_, THB>(P));
     size_t lds = col_lds_bytes<M_, THB>(P, dl);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = dl ? solve_col_kernel<M_, THB, DLmax> : solve_col_kernel<M_, THB, 0>;
+    auto kern = lat ? solve_col_kernel<M_, THB, DLlat, 128> : (dl ? solve_col_kernel<M_, THB, DLmax, 64> : solve_col_kernel<M_, THB, 0, 64>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(lat ? 128 : 64), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
     return hipGetLastError();
 }
 template <int M_> static hipError_t launch3_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
-                                              int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+                                              int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
 {
-    return P.thb ? launch3_mt<M_, 1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st)
-                 : launch3_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    return P.thb ? launch3_mt<M_, 1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape)
+                 : launch3_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 }
 
+// shape: 0 = throughput (one wavefront per instance), 1 = latency (two wavefronts per instance, see the kernel)
 hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
-                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st)
+                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
 {
     switch (m) {
 #ifndef NMPC_COL_ONLY_M
-    case 1: return launch3_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 2: return launch3_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 3: return launch3_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 4: return launch3_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 5: return launch3_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 6: return launch3_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 8: return launch3_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
-    case 10: return launch3_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 1: return launch3_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 2: return launch3_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 3: return launch3_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 4: return launch3_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 5: return launch3_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 6: return launch3_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 8: return launch3_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 10: return launch3_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 #else
-    case NMPC_COL_ONLY_M: return launch3_m<NMPC_COL_ONLY_M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case NMPC_COL_ONLY_M: return launch3_m<NMPC_COL_ONLY_M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 #endif
     default: return hipErrorInvalidValue;
     }
 }
 
-// LDS bytes one instance of the column-per-lane kernel needs (0 if m is not supported)
-size_t col_kernel_bytes(const KParams &P, int m)
+// LDS bytes one instance of the column-per-lane kernel needs in the given shape (0 if m is not supported)
+size_t col_kernel_bytes(const KParams &P, int m, int shape)
 {
-#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, col_duals_in_lds<M, 1>(P)) : col_lds_bytes<M, 0>(P, col_duals_in_lds<M, 0>(P));
+#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 1>(P)) : col_lds_bytes<M, 0>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 0>(P));
     switch (m) {
         LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(8) LB(10)
     default: return 0;

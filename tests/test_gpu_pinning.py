@@ -281,8 +281,9 @@ def test_step_batch_equals_the_separate_calls(built):
 
 
 def test_kernel_selection_by_team_size_and_batch(built):
-    """nmpc_solve_batch picks the column-per-lane kernel (3) for throughput batches and the multi-wave element-per-lane shapes (2) where a
-    batch cannot fill its slots (measured crossovers); NMPC_KERNEL pins one; horizons beyond the LDS fall back to 1."""
+    """nmpc_solve_batch picks the column-per-lane kernel in its throughput shape (3) for batches that fill the chip and in its latency shape
+    (4: two wavefronts per instance) where the launch lasts as long as its longest solve (measured crossovers: up to twice the
+    1024 / 512 instances that shape holds at once; from four robots on); NMPC_KERNEL pins one; horizons beyond the LDS fall back to 1."""
     import nmpc_amd
     def choice(ocfg, B, kernel=None, max_batch=8192):
         import os
@@ -297,9 +298,12 @@ def test_kernel_selection_by_team_size_and_batch(built):
             if old is not None:
                 os.environ["NMPC_KERNEL"] = old
     assert choice(R.cfg_two(20), [1, 512, 4096]) == [3, 3, 3]
-    assert choice(R.cfg_six(20), [1, 512, 513, 4096]) == [2, 2, 3, 3]
-    assert choice(R.cfg_ten(20), [256, 257, 1024, 4096]) == [2, 3, 3, 3]
+    assert choice(R.cfg_six(20), [1, 512, 2048, 2049, 4096]) == [4, 4, 4, 3, 3]
+    assert choice(R.cfg_ten(20), [256, 1024, 1025, 4096]) == [4, 4, 3, 3]
+    c8 = R.cfg_six(25); c8.obstacles = [(0.3 * i, 0.0, 0.1) for i in range(8)]; c8.rob_dim = 0.2; c8.margin = 0.1
+    assert choice(c8, [1024, 1025]) == [4, 3]                # eight obstacles: 63 KB of LDS per instance with its duals, 512 at once
     assert choice(R.cfg_six(20), [1, 4096], kernel="3") == [3, 3] and choice(R.cfg_six(20), [1, 4096], kernel="2") == [2, 2]
+    assert choice(R.cfg_six(20), [1, 4096], kernel="4") == [4, 4]
     # the column kernel keeps only what the sweeps touch in LDS: six robots fit up to ~190 stages (element-per-lane kernel: 88)
     assert choice(R.cfg_six(120), [1, 64], max_batch=64) == [3, 3]
     assert choice(R.cfg_six(240), [1, 64], max_batch=64) == [1, 1]          # beyond the LDS of either LDS kernel: HBM-resident fallback

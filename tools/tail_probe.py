@@ -7,7 +7,7 @@ import nmpc_amd, bench
 from tests import helpers as Hh
 ocfg, B, P, W0 = bench.make_batch("six", 0)
 cfg = Hh.to_product_cfg(ocfg)
-os.environ["NMPC_KERNEL"] = "3"
+os.environ["NMPC_KERNEL"] = os.environ.get("TAIL_KERNEL", "3")
 s = nmpc_amd.NmpcSolver(cfg, max_batch=B)
 def run(P, W0, tag):
     dP = torch.as_tensor(P, device="cuda"); dW = torch.as_tensor(W0, device="cuda")
