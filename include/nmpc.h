@@ -115,11 +115,14 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
  *   NMPC_QUERY_WORKSPACE_BYTES   device workspace held by the handle (same as nmpc_workspace_bytes)
  *   NMPC_QUERY_LDS_BYTES         arg = B: dynamic LDS per swarm instance of that kernel (0 for the HBM-resident kernel's fixed carve-up)
  *   NMPC_QUERY_MAX_BATCH         the max_batch the handle was created for
+ *   NMPC_QUERY_KERNEL_FOR_ORDERED_BATCH  arg = B: as NMPC_QUERY_KERNEL_FOR_BATCH for a call that carries a dispatch-order hint
+ *                                (nmpc_solve_batch_ordered, nmpc_step_batch): the latency shape is kept for larger batches then
  */
 #define NMPC_QUERY_KERNEL_FOR_BATCH 1
 #define NMPC_QUERY_WORKSPACE_BYTES 2
 #define NMPC_QUERY_LDS_BYTES 3
 #define NMPC_QUERY_MAX_BATCH 4
+#define NMPC_QUERY_KERNEL_FOR_ORDERED_BATCH 5
 int64_t nmpc_query(const nmpc_handle_t *h, int32_t what, int64_t arg);
 
 /* bytes of device workspace held by the handle */

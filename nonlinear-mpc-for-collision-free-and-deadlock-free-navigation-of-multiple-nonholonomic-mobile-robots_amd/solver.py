@@ -119,9 +119,10 @@ class NmpcSolver:
     def workspace_bytes(self) -> int:
         return int(self.lib.nmpc_workspace_bytes(self._h))
 
-    def kernel_for_batch(self, B: int) -> int:
-        """the solve kernel nmpc_solve_batch launches for a batch of B: 3 column-per-lane, 2 element-per-lane, 1 HBM-resident (nmpc_query)"""
-        return int(self.lib.nmpc_query(self._h, _lib.QUERY_KERNEL_FOR_BATCH, int(B)))
+    def kernel_for_batch(self, B: int, ordered: bool = False) -> int:
+        """the solve kernel nmpc_solve_batch launches for a batch of B (ordered: with a dispatch-order hint): 3 / 4 column-per-lane in its
+        throughput / latency shape, 2 element-per-lane, 1 HBM-resident (nmpc_query)"""
+        return int(self.lib.nmpc_query(self._h, 5 if ordered else _lib.QUERY_KERNEL_FOR_BATCH, int(B)))
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

@@ -304,6 +304,8 @@ def test_kernel_selection_by_team_size_and_batch(built):
     assert choice(c8, [1024, 1025]) == [4, 3]                # eight obstacles: 63 KB of LDS per instance with its duals, 512 at once
     assert choice(R.cfg_six(20), [1, 4096], kernel="3") == [3, 3] and choice(R.cfg_six(20), [1, 4096], kernel="2") == [2, 2]
     assert choice(R.cfg_six(20), [1, 4096], kernel="4") == [4, 4]
+    s6 = nmpc_amd.NmpcSolver(Hh.to_product_cfg(R.cfg_six(20)), max_batch=8192)
+    assert [s6.kernel_for_batch(b, ordered=True) for b in (2048, 4096, 4097)] == [4, 4, 3]      # with an order hint: up to four rounds
     # the column kernel keeps only what the sweeps touch in LDS: six robots fit up to ~190 stages (element-per-lane kernel: 88)
     assert choice(R.cfg_six(120), [1, 64], max_batch=64) == [3, 3]
     assert choice(R.cfg_six(240), [1, 64], max_batch=64) == [1, 1]          # beyond the LDS of either LDS kernel: HBM-resident fallback
