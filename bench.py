@@ -167,9 +167,12 @@ def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id, wname="s
         pdir = PROFILE_DIR.get(wname, "current")
         tj = json.load(open(os.path.join(ROOT, "profiles", pdir, "hbm_traffic.json")))
         same_lib = tj.get("library_src_hash") and ("src=" + tj["library_src_hash"]) in lib_version
-        if same_lib and tj["workload"].get("m") == ocfg.m and tj["workload"].get("N") == ocfg.N and tj["workload"].get("batch_per_gpu") == B:
+        if same_lib and tj["workload"].get("m") == ocfg.m and tj["workload"].get("N") == ocfg.N:
+            # bytes per interior-point iteration and instance do not depend on the batch size (every instance works on its own workspace); an
+            # entry at another batch than the profile's says so
             rl["traffic"] = tj["hbm_bytes_per_iteration"] * float(sum_iters)
-            rl["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch" % (pdir, tj["library_src_hash"])
+            rl["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch%s" % (
+                pdir, tj["library_src_hash"], "" if tj["workload"].get("batch_per_gpu") == B else " (profile taken at batch %s)" % tj["workload"].get("batch_per_gpu"))
             rl["traffic_GBps"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9
         else:
             rl["traffic_source"] = "null: profiles/%s/hbm_traffic.json was taken from another build or workload (src=%s)" % (pdir, tj.get("library_src_hash"))

@@ -148,6 +148,29 @@ def test_shard_range_partitions_contiguously(built):
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_strong_scaling_shards_partition_one_global_batch():
+    """bench.py --scaling strong: every rank draws the SAME global batch (rank-independent stream) and keeps its contiguous shard — the shards
+    of all ranks concatenate to the batch one rank draws alone (BASELINE configs 4 / 5: 4096 or 8192 instances over 8 GPUs)."""
+    import importlib.util
+    import nmpc_amd
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    total, world = 203, 8
+    ocfg, B, P, W0 = bench.make_batch("two", 0, total)
+    assert B == total and P.shape[0] == total
+    parts = []
+    for rank in range(world):
+        lo, hi = nmpc_amd.shard_range(total, rank, world)
+        oc, b, p, w = bench.make_batch("two", rank, total, shard=(lo, hi))
+        assert b == hi - lo and p.shape == (b, 2 * ocfg.nx) and w.shape == (b, ocfg.n_var)
+        parts.append((p, w))
+    np.testing.assert_array_equal(np.concatenate([p for p, _ in parts]), P)
+    np.testing.assert_array_equal(np.concatenate([w for _, w in parts]), W0)
+    # weak scaling: every rank its own instances
+    assert not np.array_equal(bench.make_batch("two", 1, 16)[2], bench.make_batch("two", 0, 16)[2])
+    assert bench.STRONG_TOTAL["ten"] == 4096 and bench.STRONG_TOTAL["composite"] == 8192
+
+
 def test_gather_results_gloo_world2(tmp_path):
     """the only collective of the multi-GPU path (result gather) rehearsed with gloo on CPU, world_size 2."""
     script = tmp_path / "w.py"

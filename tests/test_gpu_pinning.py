@@ -198,6 +198,20 @@ def test_create_rejects_bad_configs(built):
     assert rc(m=7) == -2 and rc(m=9) == -2
     assert L.nmpc_n_var(None) == -1 and L.nmpc_n_g(None) == -1 and L.nmpc_n_p(None) == -1
     assert rc() == 0
+    # nmpc_create_opts / nmpc_query: options are validated, queries answer for batches the handle can take
+    cc = nmpc_amd.centralized_six_robots(20).to_c()
+    for kern, want in ((0, 0), (4, 0), (5, -1), (-1, -1)):
+        o = nmpc_amd._lib.COptions(kernel=kern, trace_instance=-1)
+        h2 = C.c_void_p()
+        assert L.nmpc_create_opts(C.byref(cc), 64, C.byref(o), C.byref(h2)) == want, kern
+        if want == 0:
+            assert L.nmpc_query(h2, nmpc_amd._lib.QUERY_MAX_BATCH, 0) == 64
+            assert L.nmpc_query(h2, nmpc_amd._lib.QUERY_KERNEL_FOR_BATCH, 64) == 4 and L.nmpc_query(h2, nmpc_amd._lib.QUERY_KERNEL_FOR_BATCH, 65) == -1
+            assert L.nmpc_query(h2, nmpc_amd._lib.QUERY_WORKSPACE_BYTES, 0) == L.nmpc_workspace_bytes(h2) > 0
+            assert 30 * 1024 < L.nmpc_query(h2, nmpc_amd._lib.QUERY_LDS_BYTES, 64) <= 40 * 1024      # latency shape: iterate + slacks / duals
+            assert L.nmpc_query(h2, 99, 0) == -1 and L.nmpc_query(None, 1, 0) == -1
+            assert L.nmpc_destroy(h2) == 0
+    assert L.nmpc_create_opts(C.byref(cc), 64, None, C.byref(h)) == 0 and L.nmpc_destroy(h) == 0
     L.nmpc_destroy(h)
 
 
