@@ -198,6 +198,7 @@ def test_create_rejects_bad_configs(built):
     assert rc(m=7) == -2 and rc(m=9) == -2
     assert L.nmpc_n_var(None) == -1 and L.nmpc_n_g(None) == -1 and L.nmpc_n_p(None) == -1
     assert rc() == 0
+    assert L.nmpc_destroy(h) == 0
     # nmpc_create_opts / nmpc_query: options are validated, queries answer for batches the handle can take
     cc = nmpc_amd.centralized_six_robots(20).to_c()
     for kern, want in ((0, 0), (4, 0), (5, -1), (-1, -1)):
@@ -212,7 +213,6 @@ def test_create_rejects_bad_configs(built):
             assert L.nmpc_query(h2, 99, 0) == -1 and L.nmpc_query(None, 1, 0) == -1
             assert L.nmpc_destroy(h2) == 0
     assert L.nmpc_create_opts(C.byref(cc), 64, None, C.byref(h)) == 0 and L.nmpc_destroy(h) == 0
-    L.nmpc_destroy(h)
 
 
 def test_longest_lds_horizon_in_every_launch_shape(built):
