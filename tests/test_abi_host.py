@@ -300,6 +300,24 @@ def test_script_presets_hold_the_scripts_literals(built):
         nmpc_amd.script_preset("no_such_script")
 
 
+def test_row_paired_layout_emulation_matches_the_one_row_layout():
+    """tools/rp_emu.py: the row-paired backward sweep of csrc/nmpc_solve_col.hip written out lane by lane in numpy (64 lanes, two rows per
+    register, row_newbcast / permlane16_swap / permlane32_swap / bpermute / readlane as index arithmetic) against tools/lane_emu.py's emulation
+    of the one-row-per-register sweep on random stage packs, two to six robots (odd teams leave the upper half's last robot slot empty): the
+    pivot rows the forward sweep reads and the cost-to-go handed to the next stage agree to rounding."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rp_emu
+    from lane_emu import lane_sweep
+    rng = np.random.default_rng(3)
+    for m in (2, 3, 4, 5, 6):
+        N = 3
+        pk, off = rp_emu.random_packs(m, N, rng)
+        ref = lane_sweep(pk, m, N, 3 * m, 2 * m, off)
+        got, Pk, pv = rp_emu.rp_sweep(pk, m, N, off)
+        err = max(np.abs(ref[k] - got[k]).max() / max(1.0, np.abs(ref[k]).max()) for k in range(N))
+        assert err < 1e-13 and np.abs(Pk - Pk.T).max() < 1e-12, (m, err)
+
+
 def _col_kernel_asm(tmp_path, m):
     """gfx950 assembly of the column kernel instantiated for one team size (hipcc cross-compiles here)"""
     import importlib
