@@ -360,3 +360,27 @@ def test_cross_lane_instruction_semantics_on_device(built, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout)
     assert out.returncode == 0 and "as expected" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal(built, scaling):
+    """the N > 1 path of bench.py on the one-GPU box — `--gpus 2` starts its own two ranks (torch.distributed.run on
+    127.0.0.1), NMPC_BENCH_REHEARSAL=1 puts both on device 0 with the gloo backend (the nccl branch needs two devices): barrier + max-over-ranks
+    timing, the result gather checked against the local shard, ONE JSON line from rank 0.  weak: every rank its own batch; strong: one global
+    batch sharded with shard_range (BASELINE configs 4 / 5)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMPC_BENCH_REHEARSAL="1")
+    env.pop("NMPC_KERNEL", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--sweep", "0", "--cpu-sample", "0",
+           "--closed-loop", "0", "--workload", "two", "--scaling", scaling] + (["--batch-total", "300"] if scaling == "strong" else ["--batch", "128"])
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo" and d["scaling"] == scaling
+    assert d["value"] > 0 and d["solve_stats"]["converged_frac"] == 1.0 and d["gather"]["ms"] > 0
+    assert d["config"]["batch_total"] == (300 if scaling == "strong" else 256) and d["config"]["batch_per_gpu"] == (150 if scaling == "strong" else 128)
