@@ -107,6 +107,15 @@ if __name__ == "__main__":
     if "two" in want: make("two", c2, P2)
     if "obs3" in want: make("obs3", co, [np.array([0.0, 0.2 + 0.1 * t, 1.2, 0.2 * t, 2.6, 1.57]) for t in range(4)])
     if "three" in want: make("three", c3, P3)
+    # pair rows AND obstacle rows in one NLP (the composite's row types): three robots crossing a field of two obstacles; own stream
+    if "mix3" in want:
+        cm = Hh.cfg_mix3(10); rm = np.random.Generator(np.random.PCG64(Hh.SEED0 + 333))
+        Pm = []
+        for _ in range(4):
+            s = rm.uniform(-0.15, 0.15, (3, 2)) + np.array([[-0.6, -0.5], [1.0, -0.4], [0.2, 1.2]])
+            gq = rm.uniform(-0.15, 0.15, (3, 2)) + np.array([[0.9, 0.7], [-0.6, 0.6], [0.1, -0.7]])
+            Pm.append(np.concatenate([np.concatenate([s, rm.uniform(-np.pi, np.pi, (3, 1))], axis=1).reshape(-1), np.concatenate([gq, rm.uniform(-np.pi, np.pi, (3, 1))], axis=1).reshape(-1)]))
+        make("mix3", cm, Pm)
     # the headline configuration (BASELINE configs[2]): the literal antipodal swap of C6:364-388 plus four drawn instances,
     # and two ten-robot instances at the file's own horizon N=20; own generator streams so that the
     # small sets above stay byte-identical

@@ -6,6 +6,12 @@ from oracle import nlp_ref as R
 SEED0 = 20210141
 
 
+def cfg_mix3(N=10):
+    """the two row types of the synthetic composite (BASELINE config 5) at a size SLSQP solves: three robots' pair rows (C6:288-306) plus two
+    circular obstacles (third_scenario_mpc_obstacle_avoidance.py:145-150), literals of C6 / the composite"""
+    return R.NLPConfig(m=3, N=N, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5, rob_dim=0.2, margin=0.1, obstacles=[(0.45, 0.1, 0.15), (-0.3, 0.5, 0.125)])
+
+
 def sample_points(rng, m, dsep, lim=2.0, obstacles=(), clear=0.0):
     pts = []
     while len(pts) < m:
