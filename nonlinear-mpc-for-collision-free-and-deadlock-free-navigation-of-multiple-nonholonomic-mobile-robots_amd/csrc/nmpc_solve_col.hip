@@ -147,6 +147,15 @@ __global__ __launch_bounds__(TPBK, (M_ <= 3 ? NMPC_COL_WAVES_SMALL : (M_ <= 6 ? 
     const double *wi = w0 + inst * (size_t)P.nvar;
     double *wo = w_out + inst * (size_t)P.nvar;
 
+#ifdef NMPC_POISON
+    {   // debug build: every LDS word and the instance's HBM workspace start as NMPC_POISON, so that a read of anything this solve did not
+        // write shows up as a parity failure instead of depending on what ran on the CU before
+        const int nl = (int)((DL ? SUU + N * NU : RED + 8) - sm);
+        for (int e = tid; e < nl; e += TPB) sm[e] = NMPC_POISON;
+        for (size_t e = tid; e < (size_t)P.stride2; e += TPB) ws[inst * P.stride2 + e] = NMPC_POISON;
+        __syncthreads();
+    }
+#endif
 #ifdef NMPC_PROFILE
     long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = clock64();
