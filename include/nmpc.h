@@ -103,8 +103,9 @@ int32_t nmpc_destroy(nmpc_handle_t *h);
  */
 typedef struct nmpc_options {
     int32_t kernel;         /* 0: the library picks the solve kernel per batch size (default).  1 HBM-resident, 2 element-per-lane,
-                               3 column-per-lane in its throughput shape (one wavefront per instance), 4 column-per-lane in its latency
-                               shape (two wavefronts per instance): that kernel for every batch size it can run (tests, A/B measurements) */
+                               3 column-per-lane in its throughput shape (one wavefront per instance), 4 / 5 column-per-lane in its latency
+                               shape with two / four wavefronts per instance (four: five and six robots, else two): that kernel for every
+                               batch size it can run (tests, A/B measurements)                                                         */
     int32_t trace_instance; /* -DNMPC_PROFILE builds: instance whose per-iteration trace is recorded (include/nmpc_debug.h); -1 none */
 } nmpc_options_t;
 int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out);

@@ -23,6 +23,8 @@ struct nmpc_handle {
     int col_lat;         // column kernel shape pin: 1 latency, -1 throughput, 0 by batch size
     bool col_lat_ok;     // the column kernel's latency shape (two wavefronts per instance, duals in LDS up to six robots) fits the LDS
     int32_t lat_slots;   // instances of that shape the device holds at once
+    int32_t lat_slots4;  // the same for four wavefronts per instance (2 per CU at 256 VGPRs per wave)
+    int lat_waves;       // 0: two or four wavefronts by the rule of lat_waves_shape(); 2 / 4: pinned (nmpc_options_t.kernel = 4 / 5)
     int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
     int32_t *it_buf;     // [max_batch] iteration counts of nmpc_step_batch when the caller passes iters == NULL
 };
@@ -99,7 +101,7 @@ int32_t nmpc_create(const nmpc_config_t *cfg, int32_t max_batch, nmpc_handle_t *
 int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc_options_t *opts, nmpc_handle_t **out)
 {
     if (!cfg || !out || max_batch < 1) return NMPC_E_ARG;
-    if (opts && (opts->kernel < 0 || opts->kernel > 4)) return NMPC_E_ARG;
+    if (opts && (opts->kernel < 0 || opts->kernel > 5)) return NMPC_E_ARG;
     if (cfg->N < 2 || cfg->N > 4096 || cfg->n_obs < 0 || cfg->n_obs > NMPC_MAX_OBSTACLES) return NMPC_E_ARG;
     if (!(cfg->T > 0.0) || !(cfg->v_max > 0.0) || !(cfg->w_max > 0.0) || !(cfg->xy_max > 0.0) || !(cfg->th_max > 0.0)) return NMPC_E_ARG;
     if (!(cfg->tol > 0.0) || !(cfg->mu_init > 0.0) || cfg->max_iter < 0) return NMPC_E_ARG;
@@ -119,8 +121,9 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
     fill_params(cfg, &h->P);
     h->max_batch = max_batch;
     const int pin = opts ? opts->kernel : 0;      // 0: chosen per batch size (kernel_for_batch)
-    h->kernel = pin ? (pin == 4 ? 3 : pin) : 3;
-    h->col_lat = pin == 4 ? 1 : (pin == 3 ? -1 : 0);      // 1: latency shape always, -1: throughput shape always, 0: by batch size
+    h->kernel = pin ? (pin >= 4 ? 3 : pin) : 3;
+    h->col_lat = pin >= 4 ? 1 : (pin == 3 ? -1 : 0);      // 1: latency shape always, -1: throughput shape always, 0: by batch size
+    h->lat_waves = pin == 4 ? 2 : (pin == 5 ? 4 : 0);
     // horizons whose iterate does not fit the 160 KB of LDS of a CU run on the HBM-resident kernel (same algorithm, slower)
     if (h->kernel == 3 && nmpc::col_kernel_bytes(h->P, cfg->m, 0) > (size_t)160 * 1024) h->kernel = 2;
     {
@@ -131,9 +134,10 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         const int by_regs = cfg->m <= 6 ? 4 : 2, by_lds = h->col_lat_ok ? (int)((size_t)160 * 1024 / lb) : 0;
         h->lat_slots = cus * (by_lds < by_regs ? by_lds : by_regs);
+        h->lat_slots4 = cus * (by_lds < 2 ? by_lds : 2);
     }
     if (h->kernel == 2 && nmpc::lds_kernel_bytes(h->P, cfg->m) > (size_t)160 * 1024) h->kernel = 1;
-    h->lat_ok = pin != 3 && pin != 4 && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
+    h->lat_ok = pin != 3 && pin < 4 && nmpc::lds_kernel_bytes(h->P, cfg->m) <= (size_t)160 * 1024;      // NMPC_KERNEL=3 pins the column kernel for every batch size
     nmpc::lds_kernel_workspace(h->P, cfg->m, &h->P.oPACK, &h->P.oKT, &h->P.stride2);
     {   // slack / dual arrays of the column kernel: pair, obstacle, control-bound (slacks + duals) and state-bound (duals) rows
         const int64_t N = cfg->N, N1 = N + 1, m = cfg->m, NPd = m * (m - 1) / 2, MK = m * cfg->n_obs, NU = 2 * m, NXB = h->P.nxb;
@@ -190,6 +194,15 @@ static int kernel_for_batch(const nmpc_handle_t *h, int32_t B, bool ordered = fa
     return kern;
 }
 
+// latency shape: two wavefronts per instance (1), or four (2) for five / six robots whose stage-parallel phases have more than 1000 items
+// (obstacle rows: (N-1) m K) while the batch fits twice the instances that shape holds at once (2 per CU)
+static int lat_waves_shape(const nmpc_handle_t *h, int32_t B)
+{
+    if (h->lat_waves == 2 || h->lat_waves == 4) return h->lat_waves == 4 ? 2 : 1;
+    const int64_t items = (int64_t)(h->cfg.N - 1) * h->cfg.m * h->cfg.n_obs;
+    return (h->cfg.m >= 5 && h->cfg.m <= 6 && items > 1000 && B <= 2 * h->lat_slots4) ? 2 : 1;
+}
+
 static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                           int32_t *iters, double *kkt, const int32_t *order, void *stream)
 {
@@ -211,7 +224,7 @@ static int32_t solve_impl(nmpc_handle_t *h, int32_t B, const double *p, const do
     const int kern = kernel_for_batch(h, B, order != nullptr);
     hipError_t e = (kern == 1)   ? nmpc::launch_solve(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, (hipStream_t)stream)
                    : (kern == 2) ? nmpc::launch_solve_lds(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream)
-                                 : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream, kern == 4);
+                                 : nmpc::launch_solve_col(P, h->cfg.m, B, p, w0, w_out, obj, status, iters, kkt, h->ws, h->prof, (hipStream_t)stream, kern == 4 ? lat_waves_shape(h, B) : 0);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 

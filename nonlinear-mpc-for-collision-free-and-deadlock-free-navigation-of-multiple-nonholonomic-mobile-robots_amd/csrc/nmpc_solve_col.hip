@@ -83,7 +83,7 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
 }
 
-// TPBK: threads per instance.  64 = the throughput shape (one wavefront per instance).  128 = the LATENCY shape: a second wavefront shares
+// TPBK: threads per instance.  64 = the throughput shape (one wavefront per instance).  128 (256) = the LATENCY shape: a second wavefront (three more) shares
 // the stage-parallel phases (evaluation, optimality error, stage packs, step lengths, multipliers, merit function, update — 41 % of a lone
 // wave's iteration for six robots) and waits at a barrier while wave 0 runs the two sweeps; for batches whose launch is as long as their
 // longest solve.
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(TPBK, (M_ <= 3 ? NMPC_COL_WAVES_SMALL : (M_ <= 6 ? 
 {
     using G = G2<M_, THB>;
     constexpr int TPB = TPBK;
-    static_assert(TPBK == 64 || TPBK == 128, "one or two wavefronts per instance");
+    static_assert(TPBK == 64 || TPBK == 128 || TPBK == 256, "one, two or four wavefronts per instance");
     constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
     static_assert(NZ <= 64, "one lane per column of the augmented matrix");
@@ -1388,16 +1388,20 @@ template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B,
     // latency shape (two wavefronts per instance): slacks and duals in LDS up to six robots — occupancy is not what a launch that lasts as
     // long as its longest solve is short of — and in the workspace for eight and ten
     constexpr int DLlat = (M_ <= 6) ? 1 : 0;
-    const bool lat = shape == 1;
+    const bool lat = shape >= 1;
     const bool dl = lat ? (DLlat != 0) : (DLmax && col_duals_in_lds<M_, THB>(P));
     size_t lds = col_lds_bytes<M_, THB>(P, dl);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = lat ? solve_col_kernel<M_, THB, DLlat, 128> : (dl ? solve_col_kernel<M_, THB, DLmax, 64> : solve_col_kernel<M_, THB, 0, 64>);
+    // four wavefronts per instance (shape 2) are instantiated for five and six robots only: they pay where a phase has > 1000 items (eight
+    // obstacles: composite B=1024 28.7 k -> 33.5 k solves/s; six robots without obstacles B=512 42.3 k -> 43.4 k) and the build time counts
+    constexpr int TPB4 = (M_ == 5 || M_ == 6) ? 256 : 128;
+    if (shape == 2 && TPB4 == 128) shape = 1;
+    auto kern = shape == 2 ? solve_col_kernel<M_, THB, DLlat, TPB4> : (lat ? solve_col_kernel<M_, THB, DLlat, 128> : (dl ? solve_col_kernel<M_, THB, DLmax, 64> : solve_col_kernel<M_, THB, 0, 64>));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(lat ? 128 : 64), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(shape == 2 ? 256 : (lat ? 128 : 64)), lds, st, P, p, w0, w_out, obj, status, iters, kkt, ws, prof);
     return hipGetLastError();
 }
 template <int M_> static hipError_t launch3_m(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
@@ -1407,7 +1411,7 @@ template <int M_> static hipError_t launch3_m(const KParams &P, int B, const dou
                  : launch3_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 }
 
-// shape: 0 = throughput (one wavefront per instance), 1 = latency (two wavefronts per instance, see the kernel)
+// shape: 0 = throughput (one wavefront per instance), 1 / 2 = latency (two / four wavefronts per instance, see the kernel)
 hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
                             int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
 {

@@ -99,7 +99,7 @@ class NmpcSolver:
         self.max_batch = int(max_batch)
         with self.torch.cuda.device(self.device):
             kv = os.environ.get("NMPC_KERNEL", "")
-            opts = _lib.COptions(kernel=int(kernel) if kernel is not None else (int(kv) if kv[:1] in ("1", "2", "3", "4") else 0),
+            opts = _lib.COptions(kernel=int(kernel) if kernel is not None else (int(kv) if kv[:1] in ("1", "2", "3", "4", "5") else 0),
                                  trace_instance=int(trace_instance) if trace_instance is not None else int(os.environ.get("NMPC_TRACE_INST", "-1")))
             _lib.check(self.lib.nmpc_create_opts(C.byref(self._ccfg), self.max_batch, C.byref(opts), C.byref(self._h)), "nmpc_create_opts")
         self.n_var, self.n_g, self.n_p = cfg.n_var, cfg.n_g, cfg.n_p

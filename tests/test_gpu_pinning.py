@@ -201,7 +201,7 @@ def test_create_rejects_bad_configs(built):
     assert L.nmpc_destroy(h) == 0
     # nmpc_create_opts / nmpc_query: options are validated, queries answer for batches the handle can take
     cc = nmpc_amd.centralized_six_robots(20).to_c()
-    for kern, want in ((0, 0), (4, 0), (5, -1), (-1, -1)):
+    for kern, want in ((0, 0), (4, 0), (5, 0), (6, -1), (-1, -1)):
         o = nmpc_amd._lib.COptions(kernel=kern, trace_instance=-1)
         h2 = C.c_void_p()
         assert L.nmpc_create_opts(C.byref(cc), 64, C.byref(o), C.byref(h2)) == want, kern
