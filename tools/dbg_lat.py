@@ -11,7 +11,7 @@ sizes = [int(a) for a in sys.argv[2:]] or [1, 64, 512, 1024, 2048, 4096]
 ocfg, _, P, W0 = bench.make_batch(name, 0, max(sizes))
 cfg = Hh.to_product_cfg(ocfg)
 s3 = nmpc_amd.NmpcSolver(cfg, max_batch=max(sizes), kernel=3)
-s4 = nmpc_amd.NmpcSolver(cfg, max_batch=max(sizes), kernel=4)
+s4 = nmpc_amd.NmpcSolver(cfg, max_batch=max(sizes), kernel=int(os.environ.get("LAT_KERNEL", "4")))      # LAT_KERNEL=5: four wavefronts per instance (five / six robots)
 print("kernel ids", s3.kernel_for_batch(sizes[-1]), s4.kernel_for_batch(sizes[-1]), flush=True)
 for B in sizes:
     dP = torch.as_tensor(P[:B], device="cuda"); dW = torch.as_tensor(W0[:B], device="cuda")
