@@ -197,6 +197,25 @@ def test_lidar_edge_cases(built):
     c2 = _product(cfg); c2.Nc = cfg.N + 1
     assert L.nmpc_lidar_create(C.byref(c2.to_c()), lbx.ctypes.data_as(dp), ubx.ctypes.data_as(dp), 4, C.byref(h)) == -1
     assert L.nmpc_lidar_n_var(None) == -1
+    # scan / plant helpers of the closed loop: no obstacle -> scan_max on every ray; plant step in place of the pose part of p; bad arguments
+    pose = np.array([[0.0, 0.0, 0.3], [1.0, -0.5, 2.0]])
+    sc = s.scan_batch(pose, np.zeros((2, 0, 3))).cpu().numpy()
+    assert sc.shape == (2, cfg.R) and (sc == 3.5).all()
+    ob = (float(np.cos(0.3)), float(np.sin(0.3)), 0.25)          # on ray 0 of the first robot, one metre out
+    one = s.scan_batch(pose[:1], np.array([[ob]]), scan_max=3.5).cpu().numpy()[0]
+    ref1 = LR.scan_of_world(pose[0], [ob], cfg.R)
+    assert np.abs(one - ref1).max() <= 1e-13 and abs(one[0] - 0.75) <= 1e-12 and (one[1:] == 3.5).all()
+    assert L.nmpc_lidar_scan_batch(1, cfg.R, 1, None, None, C.c_double(3.5), None, None) == -1
+    assert L.nmpc_lidar_scan_batch(0, cfg.R, 0, None, None, C.c_double(3.5), None, None) == 0
+    assert L.nmpc_lidar_scan_batch(1, 99, 0, None, None, C.c_double(3.5), None, None) == -1
+    Pd = torch.as_tensor(P[:4], device="cuda").clone(); r4 = s.solve_batch(Pd, W0[:4])
+    want = s.plant_batch(Pd, r4["x"]).cpu().numpy()
+    u0 = r4["x"][:, cfg.ns * (cfg.N + 1): cfg.ns * (cfg.N + 1) + 2].cpu().numpy(); p0 = P[:4, :3]
+    assert np.abs(want - (p0 + cfg.T * np.stack([u0[:, 0] * np.cos(p0[:, 2]), u0[:, 0] * np.sin(p0[:, 2]), u0[:, 1]], axis=1))).max() <= 1e-15
+    assert L.nmpc_lidar_plant_batch(s._h, 4, Pd.data_ptr(), r4["x"].data_ptr(), Pd.data_ptr(), cfg.n_p, None) == 0      # in place: pose part of p
+    torch.cuda.synchronize()
+    assert np.array_equal(Pd.cpu().numpy()[:, :3], want) and np.array_equal(Pd.cpu().numpy()[:, 3:], P[:4, 3:])
+    assert L.nmpc_lidar_plant_batch(s._h, 4, Pd.data_ptr(), r4["x"].data_ptr(), Pd.data_ptr(), 2, None) == -1
 
 
 def test_hip_lidar_matches_slsqp_golden(built):

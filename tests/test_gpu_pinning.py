@@ -286,6 +286,13 @@ def test_step_batch_equals_the_separate_calls(built):
         assert torch.equal(p1, p2) and torch.equal(w1, w2), period
         o = order.cpu().numpy(); it = r1["iters"].cpu().numpy()
         assert np.array_equal(np.sort(o), np.arange(B)) and (np.diff(it[o]) <= 0).all(), (period, it[o])
+    # an empty batch is a no-op; a hint that is not a permutation is ignored (the period is solved in index order) and replaced by a valid one
+    assert s.lib.nmpc_step_batch(s._h, 0, None, None, None, None, None, None, None, None, None) == 0
+    pb, wb = p1.clone(), w1.clone(); pc, wc = p1.clone(), w1.clone()
+    bad = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rb = s.step_batch(pb, wb, bad); rc_ = s.step_batch(pc, wc, None)
+    torch.cuda.synchronize()
+    assert torch.equal(rb["x"], rc_["x"]) and torch.equal(pb, pc) and np.array_equal(np.sort(bad.cpu().numpy()), np.arange(B))
     # order == NULL and iters == NULL are accepted by the C ABI
     L = s.lib
     xs_ = torch.empty_like(w1)
