@@ -12,6 +12,10 @@ LIBDIR = os.path.join(ROOT, "lib")                # short in-tree path (see _lib
 SO = os.path.join(LIBDIR, "libnmpc_hip.so")
 INFO = os.path.join(LIBDIR, "build_info.json")    # what the last build() call did: compiled or reused, and the source hash
 SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_lidar.hip", "nmpc_api.cpp"]
+# per-source code generation switches.  nmpc_lidar.hip: machine-level loop-invariant code motion hoists the 64-bit literals of log() / sincos()
+# out of the stage loops into vector registers, the allocator then spills them and reloads each one from scratch, with a full vmcnt wait, at
+# every use (496 scratch loads in the kernel, 6 per log); without the pass they are re-materialised where used (114)
+FILE_FLAGS = {"nmpc_lidar.hip": os.environ.get("NMPC_LIDAR_FLAGS", "-mllvm -disable-machine-licm").split()}
 DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h"] + [os.path.join("..", "..", "include", h) for h in ("nmpc.h", "nmpc_lidar.h", "nmpc_constants.h", "nmpc_debug.h")]
 
 
@@ -30,7 +34,7 @@ def source_hash() -> str:
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode()); h.update(f.read())
-    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
+    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS", "NMPC_LIDAR_FLAGS"):
         h.update((k + "=" + os.environ.get(k, "")).encode())
     return h.hexdigest()[:16]
 
@@ -104,7 +108,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         if src in skip and os.path.exists(obj):
             return obj
-        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

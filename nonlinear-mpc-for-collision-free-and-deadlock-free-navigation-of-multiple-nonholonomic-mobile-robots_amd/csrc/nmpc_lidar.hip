@@ -8,9 +8,9 @@
 // eliminated through their own linearised equality rows (d = ||p - pObs||_1), so the Newton system is a 3-state Riccati
 // recursion whose matrices (5 x 5 with the held control of the move-blocked stages) fit the registers of one lane.  One
 // WAVEFRONT solves one instance: the phases that are parallel over the horizon (evaluation, optimality error, condensed stage
-// blocks, step lengths, merit function, update: ~95 % of the memory accesses) give every lane its own stages / variables of the
-// instance's contiguous workspace in HBM/L2 (coalesced, wave reductions with v_readfirstlane so that every decision is a scalar
-// branch), and the two recursions over the horizon run uniformly on all lanes with lane 0 storing.  (A first version gave every
+// blocks, step lengths, merit function, update: ~95 % of the memory accesses) give every lane its own stages of the instance's
+// component-major workspace in HBM/L2 (lane-adjacent addresses, wave reductions with v_readfirstlane so that every decision is a
+// scalar branch), and the two recursions over the horizon run uniformly on all lanes out of LDS with lane 0 storing.  (A first version gave every
 // LANE its own instance: 64 serial solves per wavefront whose every access waited on HBM, 0.5 k solves/s — slower than the CPU.)
 // Algorithm: the interior-point iteration of nmpc_kernels.hip / the oracle (barrier rule, fraction to the boundary, non-monotone
 // l1-merit search, inertia shift on the control diagonal, barrier restart).
@@ -26,16 +26,15 @@
 namespace nmpc_lidar {
 
 struct LParams {
-    int32_t N, Nc, R, ns, max_iter, nvar, ng, np;
+    int32_t N, Nc, R, ns, max_iter, nvar, ng, np, n_ineq;      // n_ineq: finite bounds of the free variables (stages 1..N and the controls)
     double T, q[3], r[2], lw, tol, mu_init;
-    const double *lb, *ub;      // device copies of the caller's lbx / ubx [n_var]
+    // device copies of the caller's lbx / ubx in the solve kernel's layout: the state part component-major [3 + R][N + 1] with the pinned
+    // stage 0 set to -+inf (no slack rows), then the controls [2 Nc]; lb0 / ub0 [3 + R]: the caller's stage-0 bounds (feasibility of x0)
+    const double *lb, *ub, *lb0, *ub0;
     int64_t S;                  // instances the workspace holds (each `total` doubles, contiguous)
-    // element offsets of the per-instance arrays
-    int64_t oV, oU, olam, oeta, oSL, oZL, oSU, oZU, oSLu, oZLu, oSUu, oZUu, odV, odU, olamn, oetan, oVt, oUt, osn, ocs, oHxx, ogx, oWd,
-        ogdv, ohuu, ogu, ohvt, oKg, okff, opo, total;
+    // element offsets of the per-instance arrays: [3 + R][N + 1] V Vt dV SL ZL SU ZU; [R][N] eta etan Wd gdv; [3][N] lam; [2 Nc] the control ones
+    int64_t oV, oU, olam, oeta, oSL, oZL, oSU, oZU, oSLu, oZLu, oSUu, oZUu, odV, odU, oetan, oVt, oUt, oWd, ogdv, total;
 };
-
-#define W_(off, i) wsb[(off) + (i)]
 
 __device__ __forceinline__ double sgn(double a) { return (double)((a > 0.0) - (a < 0.0)); }
 
@@ -51,6 +50,21 @@ __device__ __forceinline__ double push_in(double v, double lo, double hi)
     return v;
 }
 
+// sum of log(s_i), s_i > 0, accumulated as (product of the mantissas, sum of the exponents): four instructions per term instead of a log
+// (~90, a fifth of the two phases that need the barrier function), one log per wavefront at the end.  The mantissa product is renormalised
+// after every term; a term <= 0 or NaN makes the result NaN like the log would.
+struct LogSum {
+    double m = 1.0, lo = INFINITY;
+    int e = 0;
+    __device__ __forceinline__ void add(double s_)
+    {
+        const double t = m * __builtin_amdgcn_frexp_mant(s_);
+        e += __builtin_amdgcn_frexp_exp(s_) + __builtin_amdgcn_frexp_exp(t);
+        m = __builtin_amdgcn_frexp_mant(t);
+        lo = fmin(lo, s_);
+    }
+};
+
 // wave reductions whose result the compiler knows to be uniform (scalar control flow)
 __device__ __forceinline__ double uni(double v)
 {
@@ -59,61 +73,109 @@ __device__ __forceinline__ double uni(double v)
 __device__ __forceinline__ double wsum_(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return uni(v); }
 __device__ __forceinline__ double wmax_(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return uni(v); }
 __device__ __forceinline__ double wmin_(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return uni(v); }
+__device__ __forceinline__ double wlogsum_(LogSum a)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = a.m * __shfl_xor(a.m, o);
+        a.e += __shfl_xor(a.e, o) + __builtin_amdgcn_frexp_exp(t);
+        a.m = __builtin_amdgcn_frexp_mant(t);
+        a.lo = fmin(a.lo, __shfl_xor(a.lo, o));
+    }
+    const double r = fma((double)a.e, 0.693147180559945309417, log(a.m));
+    return uni((a.lo > 0.0) ? r : NAN);
+}
 
-// One wavefront per instance.  The stage-parallel phases (evaluation, optimality error, condensed blocks, step lengths, merit,
-// update) spread stages / variables over the 64 lanes (coalesced accesses of the instance's contiguous workspace, wave
-// reductions); the two recursions over the horizon (Riccati sweep with its 5 x 5 blocks in registers, forward sweep / adjoint
-// recursion) run uniformly on all lanes, lane 0 storing.
-#define N_LDS_STAGES(N_) ((N_) + 1)
+// One wavefront per instance.  Data layout: every per-stage array of the instance's workspace is COMPONENT-MAJOR ([component][stage]),
+// and every stage-parallel phase gives lane l the stages l, l + 64, ...: lane-adjacent addresses in every load (a stage-major layout made
+// each of them touch 64 cache lines), and the loops over the components of a stage are unrolled at compile time (ray count = template
+// parameter), their loads issued in chunks before the arithmetic: a phase costs a few memory round trips instead of one per component —
+// a lone wavefront's iteration is bounded by exactly those round trips.  What the serial recursions over the horizon read
+// per stage (condensed blocks, trig, pose, gains) is written straight into LDS by the phase that computes it; the recursions run
+// uniformly on all lanes, lane 0 storing to LDS, and stage-parallel passes move their results (pose step, multipliers) from there.
 #ifndef NMPC_LIDAR_UNROLL
 #define NMPC_LIDAR_UNROLL 4      // stages of the forward / adjoint recursions unrolled together: their LDS operand reads issue as one batch
 #endif
 #ifndef NMPC_LIDAR_WAVES
-#define NMPC_LIDAR_WAVES 2      // resident waves per SIMD the register budget is set for (measured: 1 -> 27.5 k, 2 -> 29.2 k, 3 -> 21.7 k, 4 -> 19.2 k solves/s)
+#define NMPC_LIDAR_WAVES 1      // resident waves per SIMD the register budget is set for.  Measured (B = 4096 / 1024): 1 -> 63.1 k / 38.4 k solves/s, 2 -> 49.2 k / 30.0 k: with 256 registers the 5 x 5 recursion and the phases around it spill into their hot loops (every reload a full vmcnt wait), and a lone wave iterates 1.9x faster than one of a pair — which is what the longest solve of a launch sees
 #endif
+#ifndef NMPC_LIDAR_CH
+#define NMPC_LIDAR_CH 5         // components of a stage whose loads are issued together
+#endif
+#ifdef NMPC_LIDAR_PROFILE      // development: cycles per phase, returned in the first entries of w_out (tools/lidar_phase_profile.py)
+#define LP(i) do { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define LP(i) do { } while (0)
+#endif
+#ifdef NMPC_LIDAR_X_NOLOG      // timing experiments (wrong results)
+#define LOGF(x) (x)
+#else
+#define LOGF(x) log(x)
+#endif
+#ifdef NMPC_LIDAR_X_NODIV
+#define DIVF(a, b) ((a) * (b))
+#else
+#define DIVF(a, b) ((a) / (b))
+#endif
+#define SV(off, k, c) wsb[(off) + (c) * NP1 + (k)]            // state-like arrays [3 + R][N + 1]
+#define RV(off, k, m) wsb[(off) + (m) * N + ((k) - 1)]        // per-ray arrays [R][N], stages 1..N
+#define LV(k, i) wsb[olam + (i) * N + ((k) - 1)]              // multipliers of the pose rows [3][N], stages 1..N
+// R_ >= 0: ray count known at compile time (10 in V3 / V4); R_ = -1: run-time count up to NMPC_LIDAR_MAX_RAYS (loops unrolled to the
+// maximum, the surplus predicated off with its loads clamped to a valid component)
+template <int R_>
 __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                           double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
                                                           int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
 {
+    constexpr int RM = R_ >= 0 ? R_ : NMPC_LIDAR_MAX_RAYS, CM = 3 + RM, CH = NMPC_LIDAR_CH;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
-    const int N = P.N, Nc = P.Nc, R = P.R, ns = P.ns;
+    const int N = P.N, Nc = P.Nc, R = R_ >= 0 ? R_ : P.R, ns = 3 + R, NP1 = N + 1;
     const double T = P.T;
     double *wsb = ws + (size_t)b * (size_t)P.total;
-    // LDS: what the three serial recursions over the horizon read per stage.  They run uniformly on all lanes and every stage
-    // depends on the one before: an L2/HBM round trip per stage (~1 us) is their whole cost when the operands come from the
-    // workspace, so a stage-parallel pass copies them here first and the recursions touch global memory only to store.
     extern __shared__ double lsm[];
     double *SB = lsm;                              // [N+1][13]  Hxx(4) gx(3) hvt sin cos pose(3)
-    double *SC = SB + (size_t)(N_LDS_STAGES(P.N)) * 13;      // [Nc][16]   u(2) huu(2) gu(2) K(6) kff(2) du(2)
-    double *SD = SC + (size_t)P.Nc * 16;           // [N+1][3]   pose step
+    double *SC = SB + (size_t)NP1 * 13;            // [Nc][16]   u(2) huu(2) gu(2) K(6) kff(2) du(2)
+    double *SD = SC + (size_t)Nc * 16;             // [N+1][3]   pose step; the adjoint recursion overwrites it with lambda+
+    double *SP = SD + (size_t)NP1 * 3;             // [R][2]     lidar points of stage 0
     const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
     double *wo = w_out + (size_t)b * P.nvar;
-    const double *lbv = P.lb, *ubv = P.ub, *lbu = P.lb + (size_t)(N + 1) * ns, *ubu = P.ub + (size_t)(N + 1) * ns;
-    int64_t oV = P.oV, oVt = P.oVt, oU = P.oU, oUt = P.oUt;
+    const double *lbS = P.lb, *ubS = P.ub, *lbu = P.lb + (size_t)NP1 * ns, *ubu = P.ub + (size_t)NP1 * ns;      // component-major, stage 0 = -+inf
+    int oV = (int)P.oV, oVt = (int)P.oVt, oU = (int)P.oU, oUt = (int)P.oUt;
+    const int odV = (int)P.odV, odU = (int)P.odU, oSL = (int)P.oSL, oZL = (int)P.oZL, oSU = (int)P.oSU, oZU = (int)P.oZU, oSLu = (int)P.oSLu, oZLu = (int)P.oZLu,
+              oSUu = (int)P.oSUu, oZUu = (int)P.oZUu, olam = (int)P.olam, oeta = (int)P.oeta, oetan = (int)P.oetan, oWd = (int)P.oWd, ogdv = (int)P.ogdv;
     const double xs0 = pp[3], xs1 = pp[4], xs2 = pp[5];
-    const int nV = (N + 1) * ns;
+    const int nV = NP1 * ns;
+    const double lw = P.lw, q0 = P.q[0], q1 = P.q[1], q2 = P.q[2];
     auto cof = [&](int k) { return k < Nc - 1 ? k : Nc - 1; };
     auto gdist = [&](int m, double x, double y, double &sx, double &sy) {
-        double ax = x - W_(P.opo, 2 * m), ay = y - W_(P.opo, 2 * m + 1);
+        double ax = x - SP[2 * m], ay = y - SP[2 * m + 1];
         sx = sgn(ax); sy = sgn(ay);
         return fabs(ax) + fabs(ay);
     };
+// component / ray c of an unrolled loop: live?  and the index its (unconditional) loads use
+#define C_ON(c) (R_ >= 0 || (c) < ns)
+#define C_IX(c, c0) (C_ON(c) ? (c) : (c0))
+#define M_ON(m) (R_ >= 0 || (m) < R)
+#define M_IX(m, m0) (M_ON(m) ? (m) : (m0))
     // ---- load the start; X_0 (pose and scan) pinned to the parameters (V4:110-111); lidar points (V4:114-118)
-    for (int e = lane; e < nV; e += 64) W_(oV, e) = (e < 3) ? pp[e] : ((e < ns) ? pp[6 + (e - 3)] : wi[e]);
-    for (int e = lane; e < 2 * Nc; e += 64) W_(oU, e) = wi[(size_t)nV + e];
+    for (int k = lane; k <= N; k += 64)
+        for (int c = 0; c < ns; c++) {
+            SV(oV, k, c) = (k == 0) ? ((c < 3) ? pp[c] : pp[6 + (c - 3)]) : wi[(size_t)k * ns + c];
+            if (k == 0) SV(odV, 0, c) = 0.0;
+        }
+    for (int e = lane; e < 2 * Nc; e += 64) wsb[oU + e] = wi[(size_t)NP1 * ns + e];
     for (int m = lane; m < R; m += 64) {
         double a = pp[2] + pp[6 + R + m], s, c;
         sincos(a, &s, &c);
-        W_(P.opo, 2 * m) = pp[0] + pp[6 + m] * c; W_(P.opo, 2 * m + 1) = pp[1] + pp[6 + m] * s;
+        SP[2 * m] = pp[0] + pp[6 + m] * c; SP[2 * m + 1] = pp[1] + pp[6 + m] * s;
     }
     __syncthreads();
     {   // the pinned stage-0 variables must respect their own bounds
         double bad = 0.0;
-        for (int c = lane; c < ns; c += 64) { double v = W_(oV, c); if (v < lbv[c] || v > ubv[c]) bad = 1.0; }
+        for (int c = lane; c < ns; c += 64) { double v = (c < 3) ? pp[c] : pp[6 + (c - 3)]; if (v < P.lb0[c] || v > P.ub0[c]) bad = 1.0; }
         if (wmax_(bad) > 0.0) {
-            for (int e = lane; e < nV; e += 64) wo[e] = W_(oV, e);
-            for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)nV + e] = W_(oU, e);
+            for (int k = lane; k <= N; k += 64) for (int c = 0; c < ns; c++) wo[(size_t)k * ns + c] = SV(oV, k, c);
+            for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)NP1 * ns + e] = wsb[oU + e];
             if (lane == 0) {
                 if (obj_out) obj_out[b] = NAN;
                 if (status_out) status_out[b] = NMPC_STATUS_INFEASIBLE_X0;
@@ -123,28 +185,35 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             return;
         }
     }
-    int n_ineq;
-    { double c = 0.0; for (int e = ns + lane; e < nV; e += 64) c += (isfinite(lbv[e]) ? 1.0 : 0.0) + (isfinite(ubv[e]) ? 1.0 : 0.0); n_ineq = 4 * Nc + (int)wsum_(c); }
+    const int n_ineq = P.n_ineq;
 
-    // objective, sum / max of the equality residuals at (oVx, oUx): one stage per lane; optionally the trig cache
-    auto eval_point = [&](int64_t oVx, int64_t oUx, bool trig, double &th, double &ec) {
+    // objective, sum / max of the equality residuals at (oVx, oUx): one stage per lane; leaves sin / cos of the point in SB (the last
+    // point evaluated in an iteration is the accepted one)
+    auto eval_point = [&](int oVx, int oUx, double &th, double &ec) {
         double f = 0.0, t_ = 0.0, e_ = 0.0;
         for (int k = lane; k < N; k += 64) {
             const int j = cof(k);
-            const double x = W_(oVx, k * ns), y = W_(oVx, k * ns + 1), t = W_(oVx, k * ns + 2), u0 = W_(oUx, 2 * j), u1 = W_(oUx, 2 * j + 1);
-            const double xn = W_(oVx, (k + 1) * ns), yn = W_(oVx, (k + 1) * ns + 1), tn = W_(oVx, (k + 1) * ns + 2);
+            const double x = SV(oVx, k, 0), y = SV(oVx, k, 1), t = SV(oVx, k, 2), u0 = wsb[oUx + 2 * j], u1 = wsb[oUx + 2 * j + 1];
+            const double xn = SV(oVx, k + 1, 0), yn = SV(oVx, k + 1, 1), tn = SV(oVx, k + 1, 2);
+            double dk[RM > 0 ? RM : 1], dn[RM > 0 ? RM : 1];
+            if (R_ > 0 || (R_ < 0 && R > 0)) {
+#pragma unroll
+                for (int m = 0; m < RM; m++) { dk[m] = SV(oVx, k, 3 + M_IX(m, 0)); dn[m] = SV(oVx, k + 1, 3 + M_IX(m, 0)); }
+            }
             double s, c;
             sincos(t, &s, &c);
-            if (trig) { W_(P.osn, k) = s; W_(P.ocs, k) = c; }
+            SB[k * 13 + 8] = s; SB[k * 13 + 9] = c;
             const double c0 = xn - (x + T * u0 * c), c1 = yn - (y + T * u0 * s), c2 = tn - (t + T * u1);
             t_ += fabs(c0) + fabs(c1) + fabs(c2); e_ = fmax(e_, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
-            f += P.q[0] * (x - xs0) * (x - xs0); f += P.q[1] * (y - xs1) * (y - xs1); f += P.q[2] * (t - xs2) * (t - xs2);
+            f += q0 * (x - xs0) * (x - xs0); f += q1 * (y - xs1) * (y - xs1); f += q2 * (t - xs2) * (t - xs2);
             f += P.r[0] * u0 * u0 + P.r[1] * u1 * u1;
-            for (int m = 0; m < R; m++) {
-                if (P.lw != 0.0) { double d = W_(oVx, k * ns + 3 + m); f += P.lw / (d * d); }
-                double sx, sy, e = W_(oVx, (k + 1) * ns + 3 + m) - gdist(m, xn, yn, sx, sy);
-                t_ += fabs(e); e_ = fmax(e_, fabs(e));
-            }
+#pragma unroll
+            for (int m = 0; m < RM; m++)
+                if (M_ON(m)) {
+                    if (lw != 0.0) { double d = dk[m]; f += lw / (d * d); }
+                    double sx, sy, e = dn[m] - gdist(m, xn, yn, sx, sy);
+                    t_ += fabs(e); e_ = fmax(e_, fabs(e));
+                }
         }
         th = wsum_(t_); ec = wmax_(e_);
         return wsum_(f);
@@ -152,6 +221,9 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
 
     double mu = P.mu_init, f = 0.0, th0 = 0.0, e_c = 0.0;
     int it = 0, n_tiny = 0, n_restart = 0, status = NMPC_STATUS_MAX_ITER;
+#ifdef NMPC_LIDAR_PROFILE
+    long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
     // cold-start retry (the restoration of last resort of the main solver, same constants; see oracle/lidar_oracle.c)
     int n_cold = 0, it_base = 0;
     bool cold = false;
@@ -163,75 +235,101 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     auto cold_retry = [&]() { cold = true; n_cold++; it_base = it; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
     for (;;) {      // (re)start of the barrier iteration
         if (cold) {       // the reference's cold start (V4:184-196): X_k = x0 (pose and scan), U = 0
-            for (int e = ns + lane; e < nV; e += 64) W_(oV, e) = W_(oV, e % ns);
-            for (int e = lane; e < 2 * Nc; e += 64) W_(oU, e) = 0.0;
+            for (int k = 1 + lane; k <= N; k += 64) for (int c = 0; c < ns; c++) SV(oV, k, c) = SV(oV, 0, c);
+            for (int e = lane; e < 2 * Nc; e += 64) wsb[oU + e] = 0.0;
             cold = false;
             __syncthreads();
         }
-        for (int e = ns + lane; e < nV; e += 64) {
-            const double lo = lbv[e], hi = ubv[e], v = push_in(W_(oV, e), lo, hi);
-            W_(oV, e) = v;
-            const double sl = isfinite(lo) ? fmax(v - lo, 1e-12) : 1.0, su = isfinite(hi) ? fmax(hi - v, 1e-12) : 1.0;
-            W_(P.oSL, e) = sl; W_(P.oZL, e) = isfinite(lo) ? mu / sl : 0.0;
-            W_(P.oSU, e) = su; W_(P.oZU, e) = isfinite(hi) ? mu / su : 0.0;
-        }
+        for (int k = lane; k <= N; k += 64)
+            for (int c = 0; c < ns; c++) {      // stage 0 is pinned: its bounds read -+inf here, its slots stay (1, 0)
+                const double lo = lbS[c * NP1 + k], hi = ubS[c * NP1 + k], v = push_in(SV(oV, k, c), lo, hi);
+                SV(oV, k, c) = v;
+                const double sl = isfinite(lo) ? fmax(v - lo, 1e-12) : 1.0, su = isfinite(hi) ? fmax(hi - v, 1e-12) : 1.0;
+                SV(oSL, k, c) = sl; SV(oZL, k, c) = isfinite(lo) ? mu / sl : 0.0;
+                SV(oSU, k, c) = su; SV(oZU, k, c) = isfinite(hi) ? mu / su : 0.0;
+            }
         for (int e = lane; e < 2 * Nc; e += 64) {
-            const double u = push_in(W_(oU, e), lbu[e], ubu[e]), sl = fmax(u - lbu[e], 1e-12), su = fmax(ubu[e] - u, 1e-12);
-            W_(oU, e) = u;
-            W_(P.oSLu, e) = sl; W_(P.oZLu, e) = mu / sl; W_(P.oSUu, e) = su; W_(P.oZUu, e) = mu / su;
+            const double u = push_in(wsb[oU + e], lbu[e], ubu[e]), sl = fmax(u - lbu[e], 1e-12), su = fmax(ubu[e] - u, 1e-12);
+            wsb[oU + e] = u;
+            wsb[oSLu + e] = sl; wsb[oZLu + e] = mu / sl; wsb[oSUu + e] = su; wsb[oZUu + e] = mu / su;
         }
-        for (int e = lane; e < (N + 1) * 3; e += 64) W_(P.olam, e) = 0.0;
-        for (int e = lane; e < (N + 1) * R; e += 64) W_(P.oeta, e) = 0.0;
+        for (int e = lane; e < N * 3; e += 64) wsb[olam + e] = 0.0;
+        for (int e = lane; e < N * R; e += 64) wsb[oeta + e] = 0.0;
         __syncthreads();
-        f = eval_point(oV, oU, true, th0, e_c);
+        f = eval_point(oV, oU, th0, e_c);
         __syncthreads();
         delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false;
 
         for (;;) {
+            LP(0);
             // ---- A. optimality error (IPOPT eq. 5): one stage per lane
             double e_d = 0.0, e_h = 0.0, zsum = 0.0, lsum = 0.0, cmax = 0.0, cmin = INFINITY, pu0 = 0.0, pu1 = 0.0;
             auto ctrl_rows = [&](int j, double ru0, double ru1) {      // stationarity / complementarity of control j given its Lagrangian gradient
                 for (int e = 0; e < 2; e++) {
                     const int o = 2 * j + e;
-                    const double zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), sl = W_(P.oSLu, o), su = W_(P.oSUu, o), u = W_(oU, o);
+                    const double zl = wsb[oZLu + o], zu = wsb[oZUu + o], sl = wsb[oSLu + o], su = wsb[oSUu + o], u = wsb[oU + o];
                     const double ru = (e ? ru1 : ru0) - (zl - zu);
                     e_d = fmax(e_d, fabs(ru)); zsum += zl + zu;
                     cmax = fmax(cmax, fmax(sl * zl, su * zu)); cmin = fmin(cmin, fmin(sl * zl, su * zu));
                     e_h = fmax(e_h, fmax(fabs((u - lbu[o]) - sl), fabs((ubu[o] - u) - su)));
                 }
             };
+            // complementarity / bound-row residual of one variable (its slots hold (1, 0) where a bound is absent)
+            auto comp = [&](double v, double lo, double hi, double sl, double zl, double su, double zu) {
+                if (isfinite(lo)) { const double pz = sl * zl; zsum += zl; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((v - lo) - sl)); }
+                if (isfinite(hi)) { const double pz = su * zu; zsum += zu; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((hi - v) - su)); }
+            };
             for (int k = lane; k <= N; k += 64) {
+                const int j = cof(k);
+                const double u0 = (k < N) ? wsb[oU + 2 * j] : 0.0, u1 = (k < N) ? wsb[oU + 2 * j + 1] : 0.0;
+                const double ln0 = (k < N) ? LV(k + 1, 0) : 0.0, ln1 = (k < N) ? LV(k + 1, 1) : 0.0, ln2 = (k < N) ? LV(k + 1, 2) : 0.0;
+                const double sn = SB[k * 13 + 8], cs = SB[k * 13 + 9];
                 if (k >= 1) {
-                    const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1), t = W_(oV, k * ns + 2);
-                    double r0 = W_(P.olam, 3 * k), r1 = W_(P.olam, 3 * k + 1), r2 = W_(P.olam, 3 * k + 2);
+                    const double x = SV(oV, k, 0), y = SV(oV, k, 1), t = SV(oV, k, 2);
+                    double r0 = LV(k, 0), r1 = LV(k, 1), r2 = LV(k, 2);
+                    double pv[3], plo[3], phi[3], psl[3], pzl[3], psu[3], pzu[3];
+                    pv[0] = x; pv[1] = y; pv[2] = t;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        plo[c] = lbS[c * NP1 + k]; phi[c] = ubS[c * NP1 + k];
+                        psl[c] = SV(oSL, k, c); pzl[c] = SV(oZL, k, c); psu[c] = SV(oSU, k, c); pzu[c] = SV(oZU, k, c);
+                    }
                     lsum += fabs(r0) + fabs(r1) + fabs(r2);
                     if (k < N) {
-                        const double l0 = W_(P.olam, 3 * k + 3), l1 = W_(P.olam, 3 * k + 4), l2 = W_(P.olam, 3 * k + 5), u0 = W_(oU, 2 * cof(k));
-                        const double a = -T * u0 * W_(P.osn, k), bq = T * u0 * W_(P.ocs, k);
-                        r0 += 2 * P.q[0] * (x - xs0) - l0; r1 += 2 * P.q[1] * (y - xs1) - l1; r2 += 2 * P.q[2] * (t - xs2) - l2;
-                        r2 -= a * l0 + bq * l1;
+                        const double a = -T * u0 * sn, bq = T * u0 * cs;
+                        r0 += 2 * q0 * (x - xs0) - ln0; r1 += 2 * q1 * (y - xs1) - ln1; r2 += 2 * q2 * (t - xs2) - ln2;
+                        r2 -= a * ln0 + bq * ln1;
                     }
-                    for (int m = 0; m < R; m++) {
-                        double sx, sy; gdist(m, x, y, sx, sy);
-                        const double et = W_(P.oeta, k * R + m), d = W_(oV, k * ns + 3 + m);
-                        r0 -= et * sx; r1 -= et * sy;
-                        double rd = et + ((k < N && P.lw != 0.0) ? -2.0 * P.lw / (d * d * d) : 0.0);
-                        rd -= W_(P.oZL, k * ns + 3 + m) - W_(P.oZU, k * ns + 3 + m);
-                        e_d = fmax(e_d, fabs(rd)); lsum += fabs(et);
-                    }
-                    r0 -= W_(P.oZL, k * ns) - W_(P.oZU, k * ns); r1 -= W_(P.oZL, k * ns + 1) - W_(P.oZU, k * ns + 1); r2 -= W_(P.oZL, k * ns + 2) - W_(P.oZU, k * ns + 2);
+#pragma unroll
+                    for (int m0 = 0; m0 < RM; m0 += CH)
+                        if (R_ >= 0 || m0 < R) {
+                            double et[CH], d[CH], lo[CH], hi[CH], sl[CH], zl[CH], su[CH], zu[CH];
+#pragma unroll
+                            for (int u = 0; u < CH; u++)
+                                if (m0 + u < RM) {
+                                    const int m = M_IX(m0 + u, m0);
+                                    et[u] = RV(oeta, k, m); d[u] = SV(oV, k, 3 + m); lo[u] = lbS[(3 + m) * NP1 + k]; hi[u] = ubS[(3 + m) * NP1 + k];
+                                    sl[u] = SV(oSL, k, 3 + m); zl[u] = SV(oZL, k, 3 + m); su[u] = SV(oSU, k, 3 + m); zu[u] = SV(oZU, k, 3 + m);
+                                }
+#pragma unroll
+                            for (int u = 0; u < CH; u++)
+                                if (m0 + u < RM && M_ON(m0 + u)) {
+                                    double sx, sy; gdist(m0 + u, x, y, sx, sy);
+                                    r0 -= et[u] * sx; r1 -= et[u] * sy;
+                                    double rd = et[u] + ((k < N && lw != 0.0) ? -2.0 * lw / (d[u] * d[u] * d[u]) : 0.0);
+                                    rd -= zl[u] - zu[u];
+                                    e_d = fmax(e_d, fabs(rd)); lsum += fabs(et[u]);
+                                    comp(d[u], lo[u], hi[u], sl[u], zl[u], su[u], zu[u]);
+                                }
+                        }
+                    r0 -= pzl[0] - pzu[0]; r1 -= pzl[1] - pzu[1]; r2 -= pzl[2] - pzu[2];
                     e_d = fmax(e_d, fmax(fabs(r0), fmax(fabs(r1), fabs(r2))));
-                    for (int c = 0; c < ns; c++) {
-                        const int e = k * ns + c;
-                        const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
-                        if (isfinite(lo)) { double sl = W_(P.oSL, e), zl = W_(P.oZL, e), pz = sl * zl; zsum += zl; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((v - lo) - sl)); }
-                        if (isfinite(hi)) { double su = W_(P.oSU, e), zu = W_(P.oZU, e), pz = su * zu; zsum += zu; cmax = fmax(cmax, pz); cmin = fmin(cmin, pz); e_h = fmax(e_h, fabs((hi - v) - su)); }
-                    }
+#pragma unroll
+                    for (int c = 0; c < 3; c++) comp(pv[c], plo[c], phi[c], psl[c], pzl[c], psu[c], pzu[c]);
                 }
                 if (k < N) {       // control rows: stage k contributes to the Lagrangian gradient of control cof(k)
-                    const int j = cof(k);
-                    const double g0 = 2 * P.r[0] * W_(oU, 2 * j) - T * (W_(P.ocs, k) * W_(P.olam, 3 * k + 3) + W_(P.osn, k) * W_(P.olam, 3 * k + 4));
-                    const double g1 = 2 * P.r[1] * W_(oU, 2 * j + 1) - T * W_(P.olam, 3 * k + 5);
+                    const double g0 = 2 * P.r[0] * u0 - T * (cs * ln0 + sn * ln1);
+                    const double g1 = 2 * P.r[1] * u1 - T * ln2;
                     if (k < Nc - 1) ctrl_rows(j, g0, g1); else { pu0 += g0; pu1 += g1; }
                 }
             }
@@ -241,7 +339,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             const double smax = 100.0;
             const double s_d = fmax(smax, (lsum + zsum) / (double)(N * ns + n_ineq)) / smax;
             const double s_c = fmax(smax, zsum / (double)(n_ineq > 0 ? n_ineq : 1)) / smax;
-            const double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c));
+            const double E0 = uni(fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmax / s_c)));
             kkt = E0;
             if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && it < P.max_iter) { cold_retry(); break; } status = NMPC_STATUS_NUMERIC; break; }
             if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
@@ -254,155 +352,171 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                 if (mu > mu_min && Emu <= 10.0 * mu) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
                 else break;
             }
-            const double tau = fmax(0.99, 1.0 - mu);
+            // wave-uniform values that live across phases go back to scalar registers (arithmetic on them runs on the vector ALU and would
+            // leave them in vector registers — the ones the allocator then spills to scratch and reloads inside the hot loops)
+            mu = uni(mu);
+            const double tau = uni(fmax(0.99, 1.0 - mu));
+            LP(1);
 
-            // ---- B0. condensed stage blocks, one stage per lane.  slot: v = mu/s - sigma (h - s), sigma = z/s
-            for (int k = 1 + lane; k <= N; k += 64) {
-                const double x = W_(oV, k * ns), y = W_(oV, k * ns + 1);
-                double H0 = 0.0, H1 = 0.0, H2 = 0.0, hd[3] = {0, 0, 0}, g[3] = {0, 0, 0};
-                if (k < N) {
-                    hd[0] = 2 * P.q[0]; hd[1] = 2 * P.q[1]; hd[2] = 2 * P.q[2];
-                    g[0] = 2 * P.q[0] * (x - xs0); g[1] = 2 * P.q[1] * (y - xs1); g[2] = 2 * P.q[2] * (W_(oV, k * ns + 2) - xs2);
-                }
-                for (int c = 0; c < ns; c++) {
-                    const int e = k * ns + c;
-                    const double v = W_(oV, e), lo = lbv[e], hi = ubv[e];
-                    double hs = 0.0, gs = 0.0;
-                    if (isfinite(lo)) { double sl = W_(P.oSL, e), sg = W_(P.oZL, e) / sl; hs += sg; gs -= mu / sl - sg * ((v - lo) - sl); }
-                    if (isfinite(hi)) { double su = W_(P.oSU, e), sg = W_(P.oZU, e) / su; hs += sg; gs += mu / su - sg * ((hi - v) - su); }
-                    if (c < 3) { hd[c] += hs; g[c] += gs; }
-                    else {
-                        const int m = c - 3;
-                        const bool cost = k < N && P.lw != 0.0;
-                        const double Wd = hs + (cost ? 6.0 * P.lw / (v * v * v * v) : 0.0), gd = gs + (cost ? -2.0 * P.lw / (v * v * v) : 0.0);
-                        W_(P.oWd, k * R + m) = Wd; W_(P.ogdv, k * R + m) = gd;
-                        double sx, sy;
-                        const double re = gdist(m, x, y, sx, sy) - v, tq = gd + Wd * re;      // linearised row: dd = G dx + re
-                        g[0] += sx * tq; g[1] += sy * tq;
-                        H0 += Wd * sx * sx; H1 += Wd * sx * sy; H2 += Wd * sy * sy;
-                    }
-                }
-                double H3 = hd[2];
-                if (k < N) H3 += T * W_(oU, 2 * cof(k)) * (W_(P.olam, 3 * k + 3) * W_(P.ocs, k) + W_(P.olam, 3 * k + 4) * W_(P.osn, k));
-                W_(P.oHxx, 4 * k) = H0 + hd[0]; W_(P.oHxx, 4 * k + 1) = H1; W_(P.oHxx, 4 * k + 2) = H2 + hd[1]; W_(P.oHxx, 4 * k + 3) = H3;
-                W_(P.ogx, 3 * k) = g[0]; W_(P.ogx, 3 * k + 1) = g[1]; W_(P.ogx, 3 * k + 2) = g[2];
-            }
-            for (int k = lane; k < N; k += 64) W_(P.ohvt, k) = T * (W_(P.olam, 3 * k + 3) * W_(P.osn, k) - W_(P.olam, 3 * k + 4) * W_(P.ocs, k));
-            for (int o = lane; o < 2 * Nc; o += 64) {
-                const int j = o >> 1, e = o & 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
-                const double sl = W_(P.oSLu, o), su = W_(P.oSUu, o), zl = W_(P.oZLu, o), zu = W_(P.oZUu, o), u = W_(oU, o);
-                W_(P.ohuu, o) = cnt * 2 * P.r[e] + zl / sl + zu / su;
-                const double vl = mu / sl - zl / sl * ((u - lbu[o]) - sl), vu = mu / su - zu / su * ((ubu[o] - u) - su);
-                W_(P.ogu, o) = cnt * 2 * P.r[e] * u - (vl - vu);
-            }
-            __syncthreads();
+            // ---- B0. condensed stage blocks, one stage per lane, straight into LDS.  slot: v = mu/s - sigma (h - s), sigma = z/s
             for (int k = lane; k <= N; k += 64) {
                 double *sb = SB + k * 13;
-                sb[0] = W_(P.oHxx, 4 * k); sb[1] = W_(P.oHxx, 4 * k + 1); sb[2] = W_(P.oHxx, 4 * k + 2); sb[3] = W_(P.oHxx, 4 * k + 3);
-                sb[4] = W_(P.ogx, 3 * k); sb[5] = W_(P.ogx, 3 * k + 1); sb[6] = W_(P.ogx, 3 * k + 2);
-                sb[7] = (k < N) ? W_(P.ohvt, k) : 0.0; sb[8] = (k < N) ? W_(P.osn, k) : 0.0; sb[9] = (k < N) ? W_(P.ocs, k) : 0.0;
-                sb[10] = W_(oV, k * ns); sb[11] = W_(oV, k * ns + 1); sb[12] = W_(oV, k * ns + 2);
+                const double x = SV(oV, k, 0), y = SV(oV, k, 1), t = SV(oV, k, 2);
+                const double sn = sb[8], cs = sb[9];
+                const double ln0 = (k < N) ? LV(k + 1, 0) : 0.0, ln1 = (k < N) ? LV(k + 1, 1) : 0.0, u0 = (k < N) ? wsb[oU + 2 * cof(k)] : 0.0;
+                sb[10] = x; sb[11] = y; sb[12] = t;
+                if (k < N) sb[7] = T * (ln0 * sn - ln1 * cs);
+                else { sb[7] = 0.0; sb[8] = 0.0; sb[9] = 0.0; }
+                if (k >= 1) {
+                    double H0 = 0.0, H1 = 0.0, H2 = 0.0, hd[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+                    if (k < N) {
+                        hd[0] = 2 * q0; hd[1] = 2 * q1; hd[2] = 2 * q2;
+                        g[0] = 2 * q0 * (x - xs0); g[1] = 2 * q1 * (y - xs1); g[2] = 2 * q2 * (t - xs2);
+                    }
+                    // Hessian / gradient contribution of the bound slots of one variable
+                    auto slots = [&](double v, double lo, double hi, double sl, double zl, double su, double zu, double &hs, double &gs) {
+                        hs = 0.0; gs = 0.0;
+                        if (isfinite(lo)) { const double sg = zl / sl; hs += sg; gs -= mu / sl - sg * ((v - lo) - sl); }
+                        if (isfinite(hi)) { const double sg = zu / su; hs += sg; gs += mu / su - sg * ((hi - v) - su); }
+                    };
+                    {
+                        const double pv[3] = {x, y, t};
+                        double plo[3], phi[3], psl[3], pzl[3], psu[3], pzu[3];
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            plo[c] = lbS[c * NP1 + k]; phi[c] = ubS[c * NP1 + k];
+                            psl[c] = SV(oSL, k, c); pzl[c] = SV(oZL, k, c); psu[c] = SV(oSU, k, c); pzu[c] = SV(oZU, k, c);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { double hs, gs; slots(pv[c], plo[c], phi[c], psl[c], pzl[c], psu[c], pzu[c], hs, gs); hd[c] += hs; g[c] += gs; }
+                    }
+#pragma unroll
+                    for (int m0 = 0; m0 < RM; m0 += CH)
+                        if (R_ >= 0 || m0 < R) {
+                            double d[CH], lo[CH], hi[CH], sl[CH], zl[CH], su[CH], zu[CH];
+#pragma unroll
+                            for (int u = 0; u < CH; u++)
+                                if (m0 + u < RM) {
+                                    const int m = M_IX(m0 + u, m0);
+                                    d[u] = SV(oV, k, 3 + m); lo[u] = lbS[(3 + m) * NP1 + k]; hi[u] = ubS[(3 + m) * NP1 + k];
+                                    sl[u] = SV(oSL, k, 3 + m); zl[u] = SV(oZL, k, 3 + m); su[u] = SV(oSU, k, 3 + m); zu[u] = SV(oZU, k, 3 + m);
+                                }
+#pragma unroll
+                            for (int u = 0; u < CH; u++)
+                                if (m0 + u < RM && M_ON(m0 + u)) {
+                                    const int m = m0 + u;
+                                    const double v = d[u];
+                                    double hs, gs;
+                                    slots(v, lo[u], hi[u], sl[u], zl[u], su[u], zu[u], hs, gs);
+                                    const bool cost = k < N && lw != 0.0;
+                                    const double Wd = hs + (cost ? 6.0 * lw / (v * v * v * v) : 0.0), gd = gs + (cost ? -2.0 * lw / (v * v * v) : 0.0);
+                                    RV(oWd, k, m) = Wd; RV(ogdv, k, m) = gd;
+                                    double sx, sy;
+                                    const double re = gdist(m, x, y, sx, sy) - v, tq = gd + Wd * re;      // linearised row: dd = G dx + re
+                                    g[0] += sx * tq; g[1] += sy * tq;
+                                    H0 += Wd * sx * sx; H1 += Wd * sx * sy; H2 += Wd * sy * sy;
+                                }
+                        }
+                    double H3 = hd[2];
+                    if (k < N) H3 += T * u0 * (ln0 * cs + ln1 * sn);
+                    sb[0] = H0 + hd[0]; sb[1] = H1; sb[2] = H2 + hd[1]; sb[3] = H3;
+                    sb[4] = g[0]; sb[5] = g[1]; sb[6] = g[2];
+                }
             }
-            for (int j = lane; j < Nc; j += 64) {
-                double *sc = SC + j * 16;
-                sc[0] = W_(oU, 2 * j); sc[1] = W_(oU, 2 * j + 1); sc[2] = W_(P.ohuu, 2 * j); sc[3] = W_(P.ohuu, 2 * j + 1);
-                sc[4] = W_(P.ogu, 2 * j); sc[5] = W_(P.ogu, 2 * j + 1);
+            for (int o = lane; o < 2 * Nc; o += 64) {
+                const int j = o >> 1, e = o & 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
+                const double sl = wsb[oSLu + o], su = wsb[oSUu + o], zl = wsb[oZLu + o], zu = wsb[oZUu + o], u = wsb[oU + o];
+                const double vl = mu / sl - zl / sl * ((u - lbu[o]) - sl), vu = mu / su - zu / su * ((ubu[o] - u) - su);
+                SC[j * 16 + e] = u;
+                SC[j * 16 + 2 + e] = cnt * 2 * P.r[e] + zl / sl + zu / su;
+                SC[j * 16 + 4 + e] = cnt * 2 * P.r[e] * u - (vl - vu);
             }
             __syncthreads();
-
+            LP(2);
             // ---- B. Riccati sweep on z = (pose (3), held control (2)) with inertia correction; uniform on all lanes, stage in registers
-            double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
+            double delta = uni(need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0);
             int ntry = 0;
             bool ok;
             for (;;) {
                 ok = true;
-                double P5[25], p5[5];
+                // Cost-to-go z' P z + 2 p' z kept as the 15 entries of its upper triangle: with At = [[A, B], [0, I]] (A = I + (a, bq) in column
+                // theta, B = [[T c, 0], [T s, 0], [0, T]]) the columns w_j = P At e_j and then M = At' P At are formed for j >= i only — 30
+                // multiply-adds instead of the 50 + 20 of the full product followed by a symmetrisation.
+                double P00, P01, P02, P03 = 0.0, P04 = 0.0, P11, P12, P13 = 0.0, P14 = 0.0, P22, P23 = 0.0, P24 = 0.0, P33 = 0.0, P34 = 0.0, P44 = 0.0;
+                double p0, p1, p2, p3 = 0.0, p4 = 0.0;
+                P00 = SB[N * 13]; P01 = SB[N * 13 + 1]; P11 = SB[N * 13 + 2]; P22 = SB[N * 13 + 3]; P02 = 0.0; P12 = 0.0;
+                p0 = SB[N * 13 + 4]; p1 = SB[N * 13 + 5]; p2 = SB[N * 13 + 6];
+                // operands of the stages: read for two stages at a time, before the gain stores of the first (the compiler keeps LDS reads behind
+                // those): one exposed LDS round trip per pair
+                auto fetch = [&](int k, double *o_, double *on_, double *oc_) {
+                    const double *sb = SB + k * 13, *sc = SC + cof(k) * 16;
 #pragma unroll
-                for (int z = 0; z < 25; z++) P5[z] = 0.0;
+                    for (int q_ = 0; q_ < 13; q_++) o_[q_] = sb[q_];
+                    on_[0] = sb[13 + 10]; on_[1] = sb[13 + 11]; on_[2] = sb[13 + 12];
 #pragma unroll
-                for (int z = 0; z < 5; z++) p5[z] = 0.0;
-                P5[0] = SB[N * 13]; P5[1] = P5[5] = SB[N * 13 + 1]; P5[6] = SB[N * 13 + 2]; P5[12] = SB[N * 13 + 3];
-                p5[0] = SB[N * 13 + 4]; p5[1] = SB[N * 13 + 5]; p5[2] = SB[N * 13 + 6];
-                for (int k = N - 1; k >= 0; k--) {
+                    for (int q_ = 0; q_ < 6; q_++) oc_[q_] = sc[q_];
+                };
+                auto stage = [&](int k, const double *o_, const double *on_, const double *oc_) -> bool {
                     const int j = cof(k);
-                    const double *sb = SB + k * 13, *sc = SC + j * 16;
-                    const double u0 = sc[0], u1 = sc[1], s = sb[8], c = sb[9], a = -T * u0 * s, bq = T * u0 * c;
-                    const double cd0 = sb[13 + 10] - (sb[10] + T * u0 * c), cd1 = sb[13 + 11] - (sb[11] + T * u0 * s),
-                                 cd2 = sb[13 + 12] - (sb[12] + T * u1);
-                    // At = [[A, B], [0, I]] acts on columns, then on rows: G = P At, M = At^T G (At is sparse: written out)
-                    double pb[5], G5[25], Mx[25], mv[5];
-#pragma unroll
-                    for (int r_ = 0; r_ < 5; r_++) {
-                        pb[r_] = p5[r_] - (P5[r_ * 5] * cd0 + P5[r_ * 5 + 1] * cd1 + P5[r_ * 5 + 2] * cd2);
-                        const double c0_ = P5[r_ * 5], c1_ = P5[r_ * 5 + 1], c2_ = P5[r_ * 5 + 2], c3_ = P5[r_ * 5 + 3], c4_ = P5[r_ * 5 + 4];
-                        G5[r_ * 5] = c0_; G5[r_ * 5 + 1] = c1_; G5[r_ * 5 + 2] = a * c0_ + bq * c1_ + c2_;
-                        G5[r_ * 5 + 3] = T * c * c0_ + T * s * c1_ + c3_; G5[r_ * 5 + 4] = T * c2_ + c4_;
-                    }
-#pragma unroll
-                    for (int q_ = 0; q_ < 5; q_++) {
-                        const double r0_ = G5[q_], r1_ = G5[5 + q_], r2_ = G5[10 + q_], r3_ = G5[15 + q_], r4_ = G5[20 + q_];
-                        Mx[q_] = r0_; Mx[5 + q_] = r1_; Mx[10 + q_] = a * r0_ + bq * r1_ + r2_;
-                        Mx[15 + q_] = T * c * r0_ + T * s * r1_ + r3_; Mx[20 + q_] = T * r2_ + r4_;
-                    }
-                    mv[0] = pb[0]; mv[1] = pb[1]; mv[2] = a * pb[0] + bq * pb[1] + pb[2]; mv[3] = T * c * pb[0] + T * s * pb[1] + pb[3]; mv[4] = T * pb[2] + pb[4];
-                    if (k >= 1) {
-                        const double h1 = sb[1];
-                        Mx[0] += sb[0]; Mx[1] += h1; Mx[5] += h1; Mx[6] += sb[2]; Mx[12] += sb[3];
-                        mv[0] += sb[4]; mv[1] += sb[5]; mv[2] += sb[6];
-                    }
-                    { const double hv = sb[7]; Mx[2 * 5 + 3] += hv; Mx[3 * 5 + 2] += hv; }
+                    const double H0 = o_[0], H1 = o_[1], H2 = o_[2], H3 = o_[3], g0 = o_[4], g1 = o_[5], g2 = o_[6], hv = o_[7], s = o_[8], c = o_[9];
+                    const double u0 = oc_[0], u1 = oc_[1], huu0 = oc_[2], huu1 = oc_[3], gu0 = oc_[4], gu1 = oc_[5];
+                    const double a = -T * u0 * s, bq = T * u0 * c, Tc = T * c, Ts = T * s;
+                    const double cd0 = on_[0] - (o_[10] + T * u0 * c), cd1 = on_[1] - (o_[11] + T * u0 * s), cd2 = on_[2] - (o_[12] + T * u1);
+                    const double pb0 = p0 - (P00 * cd0 + P01 * cd1 + P02 * cd2), pb1 = p1 - (P01 * cd0 + P11 * cd1 + P12 * cd2),
+                                 pb2 = p2 - (P02 * cd0 + P12 * cd1 + P22 * cd2), pb3 = p3 - (P03 * cd0 + P13 * cd1 + P23 * cd2),
+                                 pb4 = p4 - (P04 * cd0 + P14 * cd1 + P24 * cd2);
+                    const double w20 = a * P00 + bq * P01 + P02, w21 = a * P01 + bq * P11 + P12, w22 = a * P02 + bq * P12 + P22;
+                    const double w30 = Tc * P00 + Ts * P01 + P03, w31 = Tc * P01 + Ts * P11 + P13, w32 = Tc * P02 + Ts * P12 + P23, w33 = Tc * P03 + Ts * P13 + P33;
+                    const double w40 = T * P02 + P04, w41 = T * P12 + P14, w42 = T * P22 + P24, w43 = T * P23 + P34, w44 = T * P24 + P44;
+                    double M00 = P00, M01 = P01, M11 = P11, M02 = w20, M12 = w21, M03 = w30, M13 = w31, M04 = w40, M14 = w41;
+                    double M22 = a * w20 + bq * w21 + w22, M23 = a * w30 + bq * w31 + w32, M24 = a * w40 + bq * w41 + w42;
+                    double M33 = Tc * w30 + Ts * w31 + w33, M34 = Tc * w40 + Ts * w41 + w43, M44 = T * w42 + w44;
+                    double mv0 = pb0, mv1 = pb1, mv2 = a * pb0 + bq * pb1 + pb2, mv3 = Tc * pb0 + Ts * pb1 + pb3, mv4 = T * pb2 + pb4;
+                    if (k >= 1) { M00 += H0; M01 += H1; M11 += H2; M22 += H3; mv0 += g0; mv1 += g1; mv2 += g2; }
+                    M23 += hv;
                     if (k <= Nc - 1) {        // the stage where control j is decided carries its whole diagonal / gradient
-                        Mx[18] += sc[2] + delta; Mx[24] += sc[3] + delta;
-                        mv[3] += sc[4]; mv[4] += sc[5];
-                        const double dv = Mx[18];
-                        if (!(uni(dv) > 0.0)) { ok = false; break; }
-                        const double rdv = 1.0 / dv;          // two reciprocals per stage instead of nine divisions (the recursion is uniform: every lane pays them)
-                        const double l43 = Mx[23] * rdv, d1o = Mx[24], d1 = d1o - l43 * Mx[19];
-                        if (!(uni(d1) > 1e-9 * fabs(uni(d1o))) || !(uni(d1) > 0.0)) { ok = false; break; }
+                        M33 += huu0 + delta; M44 += huu1 + delta;
+                        mv3 += gu0; mv4 += gu1;
+                        const double dv = M33;
+                        if (!(uni(dv) > 0.0)) return false;
+                        const double rdv = 1.0 / dv;          // two reciprocals per stage (the recursion is uniform: every lane pays them)
+                        const double l43 = M34 * rdv, d1o = M44, d1 = d1o - l43 * M34;
+                        if (!(uni(d1) > 1e-9 * fabs(uni(d1o))) || !(uni(d1) > 0.0)) return false;
                         const double rd1 = 1.0 / d1;
-                        double Kk[6], kk[2];
+                        // gains: [K | kff] = -[[M33 M34], [M34 M44]]^-1 [M3q M4q | mv3 mv4], q = x, y, theta
+                        const double r3[4] = {M03, M13, M23, mv3}, r4[4] = {M04, M14, M24, mv4};
+                        double K0[4], K1[4];
 #pragma unroll
                         for (int q_ = 0; q_ < 4; q_++) {
-                            const double r3 = (q_ < 3) ? Mx[15 + q_] : mv[3], r4 = (q_ < 3) ? Mx[20 + q_] : mv[4];
-                            const double y4 = (r4 - l43 * r3) * rd1, y3 = (r3 - Mx[19] * y4) * rdv;
-                            if (q_ < 3) { Kk[q_] = -y3; Kk[3 + q_] = -y4; } else { kk[0] = -y3; kk[1] = -y4; }
+                            const double y4 = (r4[q_] - l43 * r3[q_]) * rd1, y3 = (r3[q_] - M34 * y4) * rdv;
+                            K0[q_] = -y3; K1[q_] = -y4;
                         }
                         if (lane == 0) {
                             double *sk = SC + j * 16 + 6;
-#pragma unroll
-                            for (int q_ = 0; q_ < 6; q_++) sk[q_] = Kk[q_];
-                            sk[6] = kk[0]; sk[7] = kk[1];
+                            sk[0] = K0[0]; sk[1] = K0[1]; sk[2] = K0[2]; sk[3] = K1[0]; sk[4] = K1[1]; sk[5] = K1[2]; sk[6] = K0[3]; sk[7] = K1[3];
                         }
-                        double Pn[9], pn[3];
-#pragma unroll
-                        for (int r_ = 0; r_ < 3; r_++) {
-#pragma unroll
-                            for (int q_ = 0; q_ < 3; q_++) Pn[r_ * 3 + q_] = Mx[r_ * 5 + q_] + Mx[r_ * 5 + 3] * Kk[q_] + Mx[r_ * 5 + 4] * Kk[3 + q_];
-                            pn[r_] = mv[r_] + Mx[r_ * 5 + 3] * kk[0] + Mx[r_ * 5 + 4] * kk[1];
-                        }
-#pragma unroll
-                        for (int z = 0; z < 25; z++) P5[z] = 0.0;
-#pragma unroll
-                        for (int z = 0; z < 5; z++) p5[z] = 0.0;
-#pragma unroll
-                        for (int r_ = 0; r_ < 3; r_++) {
-#pragma unroll
-                            for (int q_ = 0; q_ < 3; q_++) P5[r_ * 5 + q_] = 0.5 * (Pn[r_ * 3 + q_] + Pn[q_ * 3 + r_]);
-                            p5[r_] = pn[r_];
-                        }
+                        P00 = M00 + M03 * K0[0] + M04 * K1[0]; P01 = M01 + M03 * K0[1] + M04 * K1[1]; P02 = M02 + M03 * K0[2] + M04 * K1[2];
+                        P11 = M11 + M13 * K0[1] + M14 * K1[1]; P12 = M12 + M13 * K0[2] + M14 * K1[2]; P22 = M22 + M23 * K0[2] + M24 * K1[2];
+                        p0 = mv0 + M03 * K0[3] + M04 * K1[3]; p1 = mv1 + M13 * K0[3] + M14 * K1[3]; p2 = mv2 + M23 * K0[3] + M24 * K1[3];
+                        P03 = 0.0; P04 = 0.0; P13 = 0.0; P14 = 0.0; P23 = 0.0; P24 = 0.0; P33 = 0.0; P34 = 0.0; P44 = 0.0; p3 = 0.0; p4 = 0.0;
                     } else {                  // held control: it stays a parameter of the cost-to-go
-#pragma unroll
-                        for (int r_ = 0; r_ < 5; r_++) {
-#pragma unroll
-                            for (int q_ = 0; q_ < 5; q_++) P5[r_ * 5 + q_] = (q_ == r_) ? Mx[r_ * 5 + q_] : 0.5 * (Mx[r_ * 5 + q_] + Mx[q_ * 5 + r_]);
-                            p5[r_] = mv[r_];
-                        }
+                        P00 = M00; P01 = M01; P02 = M02; P03 = M03; P04 = M04; P11 = M11; P12 = M12; P13 = M13; P14 = M14; P22 = M22; P23 = M23; P24 = M24;
+                        P33 = M33; P34 = M34; P44 = M44;
+                        p0 = mv0; p1 = mv1; p2 = mv2; p3 = mv3; p4 = mv4;
                     }
+                    return true;
+                };
+                for (int k0 = N - 1; k0 >= 0; k0 -= 2) {
+                    double oa[13], na[3], ca[6], ob[13], nb[3], cb[6];
+                    fetch(k0, oa, na, ca); fetch(k0 >= 1 ? k0 - 1 : 0, ob, nb, cb);
+                    if (!stage(k0, oa, na, ca)) { ok = false; break; }
+                    if (k0 >= 1 && !stage(k0 - 1, ob, nb, cb)) { ok = false; break; }
                 }
                 if (ok) break;
                 ntry++;
                 if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
                 else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
+                delta = uni(delta);
                 if (delta > 1e20) break;
             }
             if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); it++; break; } status = NMPC_STATUS_NUMERIC; break; }
@@ -410,180 +524,301 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             need_shift = delta > 0.0 && (ntry > 0 || delta > 1e-6);
             __syncthreads();
 
-            // ---- C. forward sweep: the pose recursion uniform on all lanes (operands from LDS), then the R distance states of every
-            //      stage in parallel, one (stage, ray) item per lane
-            for (int c = lane; c < ns; c += 64) W_(P.odV, c) = 0.0;
+            LP(3);
+            // ---- C. forward sweep: the pose recursion uniform on all lanes (operands and results in LDS), then one stage per lane: the pose
+            //      step to the workspace, the R distance states of the stage and the multipliers eta+ of their rows
             {
+                // Stages in batches of NMPC_LIDAR_UNROLL: the LDS operands of a batch are read FIRST (the compiler does not move LDS reads across
+                // the lane-0 stores of the previous stages — one exposed LDS round trip per stage otherwise, ten times the arithmetic), then the
+                // stages are walked, then their results are stored.  Same arithmetic, stage by stage, as the plain loop.
+                constexpr int UB = NMPC_LIDAR_UNROLL;
                 double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
                 if (lane == 0) { SD[0] = 0.0; SD[1] = 0.0; SD[2] = 0.0; }
-#pragma unroll NMPC_LIDAR_UNROLL
-                for (int k = 0; k < N; k++) {
-                    const int j = cof(k);
-                    const double *sb = SB + k * 13;
-                    double *sc = SC + j * 16;
-                    if (k <= Nc - 1) {
-                        du0 = sc[12] + sc[6] * dx0 + sc[7] * dx1 + sc[8] * dx2;
-                        du1 = sc[13] + sc[9] * dx0 + sc[10] * dx1 + sc[11] * dx2;
-                        if (lane == 0) { W_(P.odU, 2 * j) = du0; W_(P.odU, 2 * j + 1) = du1; sc[14] = du0; sc[15] = du1; }
+                for (int k0 = 0; k0 < N; k0 += UB) {
+                    double s_[UB], c_[UB], px[UB + 1], py[UB + 1], pt[UB + 1], u0_[UB], u1_[UB], K_[UB][6], kf[UB][2], n_[UB][3], du_[UB][2];
+#pragma unroll
+                    for (int i = 0; i <= UB; i++) {
+                        const double *sb = SB + (k0 + i <= N ? k0 + i : N) * 13;
+                        px[i] = sb[10]; py[i] = sb[11]; pt[i] = sb[12];
+                        if (i < UB) { s_[i] = sb[8]; c_[i] = sb[9]; }
                     }
-                    const double u0 = sc[0], u1 = sc[1], s = sb[8], c = sb[9];
-                    const double xn = sb[13 + 10], yn = sb[13 + 11], tn = sb[13 + 12];
-                    const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (xn - (sb[10] + T * u0 * c));
-                    const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (yn - (sb[11] + T * u0 * s));
-                    const double n2 = dx2 + T * du1 - (tn - (sb[12] + T * u1));
-                    dx0 = n0; dx1 = n1; dx2 = n2;
+#pragma unroll
+                    for (int i = 0; i < UB; i++) {
+                        const double *sc = SC + cof(k0 + i < N ? k0 + i : N - 1) * 16;
+                        u0_[i] = sc[0]; u1_[i] = sc[1]; kf[i][0] = sc[12]; kf[i][1] = sc[13];
+#pragma unroll
+                        for (int q_ = 0; q_ < 6; q_++) K_[i][q_] = sc[6 + q_];
+                    }
+#pragma unroll
+                    for (int i = 0; i < UB; i++) {
+                        const int k = k0 + i;
+                        if (k < N) {
+                            if (k <= Nc - 1) {
+                                du0 = kf[i][0] + K_[i][0] * dx0 + K_[i][1] * dx1 + K_[i][2] * dx2;
+                                du1 = kf[i][1] + K_[i][3] * dx0 + K_[i][4] * dx1 + K_[i][5] * dx2;
+                            }
+                            const double u0 = u0_[i], u1 = u1_[i], s = s_[i], c = c_[i];
+                            const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (px[i + 1] - (px[i] + T * u0 * c));
+                            const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (py[i + 1] - (py[i] + T * u0 * s));
+                            const double n2 = dx2 + T * du1 - (pt[i + 1] - (pt[i] + T * u1));
+                            dx0 = n0; dx1 = n1; dx2 = n2;
+                            n_[i][0] = n0; n_[i][1] = n1; n_[i][2] = n2; du_[i][0] = du0; du_[i][1] = du1;
+                        }
+                    }
                     if (lane == 0) {
-                        W_(P.odV, (k + 1) * ns) = n0; W_(P.odV, (k + 1) * ns + 1) = n1; W_(P.odV, (k + 1) * ns + 2) = n2;
-                        SD[3 * (k + 1)] = n0; SD[3 * (k + 1) + 1] = n1; SD[3 * (k + 1) + 2] = n2;
+#pragma unroll
+                        for (int i = 0; i < UB; i++) {
+                            const int k = k0 + i;
+                            if (k < N) {
+                                if (k <= Nc - 1) { SC[k * 16 + 14] = du_[i][0]; SC[k * 16 + 15] = du_[i][1]; }
+                                SD[3 * (k + 1)] = n_[i][0]; SD[3 * (k + 1) + 1] = n_[i][1]; SD[3 * (k + 1) + 2] = n_[i][2];
+                            }
+                        }
                     }
                 }
             }
             __syncthreads();
-            for (int e = lane; e < N * R; e += 64) {      // dd = G dx + (g - d) at stage k1 = 1..N
-                const int k1 = 1 + e / R, m = e - (k1 - 1) * R;
-                double sx, sy;
-                const double gg = gdist(m, SB[k1 * 13 + 10], SB[k1 * 13 + 11], sx, sy);
-                W_(P.odV, k1 * ns + 3 + m) = sx * SD[3 * k1] + sy * SD[3 * k1 + 1] + (gg - W_(oV, k1 * ns + 3 + m));
-            }
-            __syncthreads();
-            // ---- multipliers of the QP: lambda+ by the adjoint recursion (uniform), eta+ from the distance rows (one per lane)
+            LP(4);
             double mult_max = 0.0;
-            {
-                double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
-#pragma unroll NMPC_LIDAR_UNROLL
-                for (int k = N; k >= 1; k--) {
-                    const double *sb = SB + k * 13;
-                    const double dx0 = SD[3 * k], dx1 = SD[3 * k + 1], dx2 = SD[3 * k + 2];
-                    const double H0 = sb[0], H1 = sb[1], H2 = sb[2], H3 = sb[3];
-                    double l0 = -(sb[4] + H0 * dx0 + H1 * dx1), l1 = -(sb[5] + H1 * dx0 + H2 * dx1), l2 = -(sb[6] + H3 * dx2);
-                    if (k < N) {
-                        const double *sc = SC + cof(k) * 16;
-                        const double u0 = sc[0];
-                        l0 += ln0; l1 += ln1;
-                        l2 += ln2 + (-T * u0 * sb[8]) * ln0 + (T * u0 * sb[9]) * ln1 - sb[7] * sc[14];
+            for (int o = lane; o < 2 * Nc; o += 64) wsb[odU + o] = SC[(o >> 1) * 16 + 14 + (o & 1)];
+            double dphi_f = 0.0;      // directional derivative of the objective (states; the controls' part is added in D)
+            for (int k = 1 + lane; k <= N; k += 64) {      // dd = G dx + (g - d);  eta+ = -(gd + Wd dd)
+                const double d0 = SD[3 * k], d1 = SD[3 * k + 1], d2 = SD[3 * k + 2], x = SB[k * 13 + 10], y = SB[k * 13 + 11];
+                SV(odV, k, 0) = d0; SV(odV, k, 1) = d1; SV(odV, k, 2) = d2;
+                if (k < N) { dphi_f += 2 * q0 * (x - xs0) * d0; dphi_f += 2 * q1 * (y - xs1) * d1; dphi_f += 2 * q2 * (SB[k * 13 + 12] - xs2) * d2; }
+#pragma unroll
+                for (int m0 = 0; m0 < RM; m0 += CH)
+                    if (R_ >= 0 || m0 < R) {
+                        double d[CH], gv[CH], wd[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if (m0 + u < RM) { const int m = M_IX(m0 + u, m0); d[u] = SV(oV, k, 3 + m); gv[u] = RV(ogdv, k, m); wd[u] = RV(oWd, k, m); }
+#pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if (m0 + u < RM && M_ON(m0 + u)) {
+                                const int m = m0 + u;
+                                double sx, sy;
+                                const double gg = gdist(m, x, y, sx, sy), dd = sx * d0 + sy * d1 + (gg - d[u]);
+                                SV(odV, k, 3 + m) = dd;
+                                if (k < N && lw != 0.0) dphi_f += -2.0 * lw / (d[u] * d[u] * d[u]) * dd;
+                                const double v = -(gv[u] + wd[u] * dd);
+                                RV(oetan, k, m) = v; mult_max = fmax(mult_max, fabs(v));
+                            }
                     }
-                    ln0 = l0; ln1 = l1; ln2 = l2;
-                    if (lane == 0) { W_(P.olamn, 3 * k) = l0; W_(P.olamn, 3 * k + 1) = l1; W_(P.olamn, 3 * k + 2) = l2; }
-                    mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
-                }
-                for (int e = R + lane; e < (N + 1) * R; e += 64) {
-                    const int k = e / R, m = e - k * R;
-                    const double v = -(W_(P.ogdv, e) + W_(P.oWd, e) * W_(P.odV, k * ns + 3 + m));
-                    W_(P.oetan, e) = v; mult_max = fmax(mult_max, fabs(v));
+            }
+            __syncthreads();
+            LP(5);
+            // ---- multipliers of the QP: lambda+ by the adjoint recursion (uniform; it replaces the pose step in SD stage by stage)
+            {
+                constexpr int UB = NMPC_LIDAR_UNROLL;      // batches as in the forward recursion: operands first, then the stages, then the stores
+                double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
+                for (int k0 = N; k0 >= 1; k0 -= UB) {
+                    double h_[UB][10], d_[UB][3], u0_[UB], du0_[UB], l_[UB][3];
+#pragma unroll
+                    for (int i = 0; i < UB; i++) {
+                        const int k = k0 - i >= 1 ? k0 - i : 1;
+                        const double *sb = SB + k * 13, *sc = SC + cof(k < N ? k : N - 1) * 16;
+#pragma unroll
+                        for (int q_ = 0; q_ < 10; q_++) h_[i][q_] = sb[q_];
+                        d_[i][0] = SD[3 * k]; d_[i][1] = SD[3 * k + 1]; d_[i][2] = SD[3 * k + 2];
+                        u0_[i] = sc[0]; du0_[i] = sc[14];
+                    }
+#pragma unroll
+                    for (int i = 0; i < UB; i++) {
+                        const int k = k0 - i;
+                        if (k >= 1) {
+                            const double dx0 = d_[i][0], dx1 = d_[i][1], dx2 = d_[i][2];
+                            const double H0 = h_[i][0], H1 = h_[i][1], H2 = h_[i][2], H3 = h_[i][3];
+                            double l0 = -(h_[i][4] + H0 * dx0 + H1 * dx1), l1 = -(h_[i][5] + H1 * dx0 + H2 * dx1), l2 = -(h_[i][6] + H3 * dx2);
+                            if (k < N) {
+                                const double u0 = u0_[i];
+                                l0 += ln0; l1 += ln1;
+                                l2 += ln2 + (-T * u0 * h_[i][8]) * ln0 + (T * u0 * h_[i][9]) * ln1 - h_[i][7] * du0_[i];
+                            }
+                            ln0 = l0; ln1 = l1; ln2 = l2;
+                            l_[i][0] = l0; l_[i][1] = l1; l_[i][2] = l2;
+                            mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
+                        }
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < UB; i++) {
+                            const int k = k0 - i;
+                            if (k >= 1) { SD[3 * k] = l_[i][0]; SD[3 * k + 1] = l_[i][1]; SD[3 * k + 2] = l_[i][2]; }
+                        }
+                    }
                 }
                 mult_max = wmax_(mult_max);
             }
-            // ---- D. fraction to the boundary; directional derivative of the barrier function (one variable per lane)
-            double a_p = 1.0, a_d = 1.0, dphi = 0.0, lgs = 0.0, thh = 0.0;
+            __syncthreads();
+            LP(6);
+            // ---- D. fraction to the boundary; directional derivative of the barrier function.  One variable per lane (the arrays of a
+            //      stage-like quantity share the flat index e = c (N+1) + k), two trips' loads issued together
+            double a_p = 1.0, a_d = 1.0, dphi = dphi_f, thh = 0.0;
+            LogSum lgs_;
             auto slot = [&](double s_, double z_, double h_, double jd_) {
-                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
-                if (ds_ < 0.0) a_p = fmin(a_p, -tau * s_ / ds_);
-                if (dz_ < 0.0) a_d = fmin(a_d, -tau * z_ / dz_);
-                dphi -= mu * ds_ / s_; lgs += log(s_); thh += fabs(h_ - s_);
+                const double ds_ = jd_ + (h_ - s_), dz_ = DIVF(mu - s_ * z_ - z_ * ds_, s_);
+                if (ds_ < 0.0) a_p = fmin(a_p, DIVF(-tau * s_, ds_));
+                if (dz_ < 0.0) a_d = fmin(a_d, DIVF(-tau * z_, dz_));
+                dphi -= DIVF(mu * ds_, s_); lgs_.add(s_); thh += fabs(h_ - s_);
             };
-            for (int e = ns + lane; e < nV; e += 64) {
-                const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
-                if (isfinite(lo)) slot(W_(P.oSL, e), W_(P.oZL, e), v - lo, dv);
-                if (isfinite(hi)) slot(W_(P.oSU, e), W_(P.oZU, e), hi - v, -dv);
-                const int k = e / ns, c = e - k * ns;
-                if (k < N) {
-                    if (c < 3) dphi += 2 * P.q[c] * (v - (c == 0 ? xs0 : (c == 1 ? xs1 : xs2))) * dv;
-                    else if (P.lw != 0.0) dphi += -2.0 * P.lw / (v * v * v) * dv;
+            {
+                auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double zl, double su, double zu) {
+                    if (isfinite(lo)) slot(sl, zl, v - lo, dv);
+                    if (isfinite(hi)) slot(su, zu, hi - v, -dv);
+                };
+                for (int e0 = lane; e0 < nV; e0 += 128) {
+                    const int e1 = e0 + 64, i1 = e1 < nV ? e1 : e0;
+                    const double v0 = wsb[oV + e0], dv0 = wsb[odV + e0], lo0 = lbS[e0], hi0 = ubS[e0], sl0 = wsb[oSL + e0], zl0 = wsb[oZL + e0], su0 = wsb[oSU + e0],
+                                 zu0 = wsb[oZU + e0];
+                    const double v1 = wsb[oV + i1], dv1 = wsb[odV + i1], lo1 = lbS[i1], hi1 = ubS[i1], sl1 = wsb[oSL + i1], zl1 = wsb[oZL + i1], su1 = wsb[oSU + i1],
+                                 zu1 = wsb[oZU + i1];
+                    item(e0, v0, dv0, lo0, hi0, sl0, zl0, su0, zu0);
+                    if (e1 < nV) item(e1, v1, dv1, lo1, hi1, sl1, zl1, su1, zu1);
                 }
             }
             for (int o = lane; o < 2 * Nc; o += 64) {
-                const double u = W_(oU, o), du = W_(P.odU, o);
-                slot(W_(P.oSLu, o), W_(P.oZLu, o), u - lbu[o], du);
-                slot(W_(P.oSUu, o), W_(P.oZUu, o), ubu[o] - u, -du);
+                const double u = wsb[oU + o], du = wsb[odU + o];
+                slot(wsb[oSLu + o], wsb[oZLu + o], u - lbu[o], du);
+                slot(wsb[oSUu + o], wsb[oZUu + o], ubu[o] - u, -du);
                 const int j = o >> 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
                 dphi += cnt * 2 * P.r[o & 1] * u * du;
             }
-            a_p = wmin_(a_p); a_d = wmin_(a_d); dphi = wsum_(dphi); lgs = wsum_(lgs); thh = wsum_(thh);
+            a_p = wmin_(a_p); a_d = wmin_(a_d); dphi = wsum_(dphi); thh = wsum_(thh);
+            const double lgs = wlogsum_(lgs_);
+            LP(7);
             // ---- E. l1 merit backtracking (non-monotone reference: max of the last merit values of this barrier problem)
-            const double theta0 = th0 + thh, phi0 = f - mu * lgs;
+            const double theta0 = uni(th0 + thh), phi0 = uni(f - mu * lgs);
             if (theta0 > 0.0) {
                 const double nut = fmin(dphi / ((1.0 - 0.1) * theta0), mult_max / (1.0 - 0.1));
                 nu_pen = fmax(1.0, 0.5 * nu_pen);
                 if (nu_pen < nut) nu_pen = nut + 1.0;
+                nu_pen = uni(nu_pen);
             }
-            const double Dm = dphi - nu_pen * theta0;
+            const double Dm = uni(dphi - nu_pen * theta0);
             double alpha = a_p, ft = f, tht = th0, ect = e_c;
             if (mh_mu != mu || mh_nu != nu_pen) { mcount = 0; mh_mu = mu; mh_nu = nu_pen; }
-            const double m0 = phi0 + nu_pen * theta0;
+            const double m0 = uni(phi0 + nu_pen * theta0);
             double mref = m0;
             if (mcount > 0) mref = fmax(mref, mh0);
             if (mcount > 1) mref = fmax(mref, mh1);
             if (mcount > 2) mref = fmax(mref, mh2);
+            mref = uni(mref);
             mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
             for (int ls = 0; ls < 30; ls++) {
-                double lgt = 0.0, tb = 0.0;
-                auto trial = [&](double s_, double h0_, double jd_, double ht_) { const double st_ = s_ + alpha * (jd_ + (h0_ - s_)); lgt += log(st_); tb += fabs(ht_ - st_); };
-                for (int e = lane; e < nV; e += 64) {
-                    const double v = W_(oV, e), dv = W_(P.odV, e), vt = v + alpha * dv;
-                    W_(oVt, e) = vt;
-                    if (e >= ns) {
-                        const double lo = lbv[e], hi = ubv[e];
-                        if (isfinite(lo)) trial(W_(P.oSL, e), v - lo, dv, vt - lo);
-                        if (isfinite(hi)) trial(W_(P.oSU, e), hi - v, -dv, hi - vt);
+                double tb = 0.0;
+                LogSum lgt_;
+                auto trial = [&](double s_, double h0_, double jd_, double ht_) { const double st_ = s_ + alpha * (jd_ + (h0_ - s_)); lgt_.add(st_); tb += fabs(ht_ - st_); };
+                {
+                    auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double su) {
+                        const double vt = v + alpha * dv;
+                        wsb[oVt + e] = vt;
+                        if (isfinite(lo)) trial(sl, v - lo, dv, vt - lo);
+                        if (isfinite(hi)) trial(su, hi - v, -dv, hi - vt);
+                    };
+                    for (int e0 = lane; e0 < nV; e0 += 128) {
+                        const int e1 = e0 + 64, i1 = e1 < nV ? e1 : e0;
+                        const double v0 = wsb[oV + e0], dv0 = wsb[odV + e0], lo0 = lbS[e0], hi0 = ubS[e0], sl0 = wsb[oSL + e0], su0 = wsb[oSU + e0];
+                        const double v1 = wsb[oV + i1], dv1 = wsb[odV + i1], lo1 = lbS[i1], hi1 = ubS[i1], sl1 = wsb[oSL + i1], su1 = wsb[oSU + i1];
+                        item(e0, v0, dv0, lo0, hi0, sl0, su0);
+                        if (e1 < nV) item(e1, v1, dv1, lo1, hi1, sl1, su1);
                     }
                 }
                 for (int o = lane; o < 2 * Nc; o += 64) {
-                    const double u = W_(oU, o), du = W_(P.odU, o), ut = u + alpha * du;
-                    W_(oUt, o) = ut;
-                    trial(W_(P.oSLu, o), u - lbu[o], du, ut - lbu[o]);
-                    trial(W_(P.oSUu, o), ubu[o] - u, -du, ubu[o] - ut);
+                    const double u = wsb[oU + o], du = wsb[odU + o], ut = u + alpha * du;
+                    wsb[oUt + o] = ut;
+                    trial(wsb[oSLu + o], u - lbu[o], du, ut - lbu[o]);
+                    trial(wsb[oSUu + o], ubu[o] - u, -du, ubu[o] - ut);
                 }
                 __syncthreads();
-                ft = eval_point(oVt, oUt, false, tht, ect);
-                lgt = wsum_(lgt); tb = wsum_(tb);
+                ft = eval_point(oVt, oUt, tht, ect);
+                const double lgt = wlogsum_(lgt_);
+                tb = wsum_(tb);
                 if ((ft - mu * lgt) + nu_pen * (tht + tb) <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
-                if (ls < 29) alpha *= 0.5;
+                if (ls < 29) alpha = uni(alpha * 0.5);
                 __syncthreads();
             }
-            a_d = fmin(a_d, alpha);
+            a_d = uni(fmin(a_d, alpha));
+            LP(8);
             n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
             // ---- G. accept: duals and slacks (they need the old primal point), then the primal point
-            auto upd = [&](int64_t oS, int64_t oZ, int e, double h_, double jd_) {
-                const double s_ = W_(oS, e), z_ = W_(oZ, e);
+            auto upd = [&](double s_, double z_, double h_, double jd_, double &sn_, double &zo_) {
                 const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
-                const double sn_ = s_ + alpha * ds_, zn_ = z_ + a_d * dz_;
-                W_(oS, e) = sn_; W_(oZ, e) = fmin(fmax(zn_, mu / (1e10 * sn_)), 1e10 * mu / sn_);
+                sn_ = s_ + alpha * ds_;
+                const double zn_ = z_ + a_d * dz_;
+                zo_ = fmin(fmax(zn_, mu / (1e10 * sn_)), 1e10 * mu / sn_);
             };
-            for (int e = ns + lane; e < nV; e += 64) {
-                const double v = W_(oV, e), dv = W_(P.odV, e), lo = lbv[e], hi = ubv[e];
-                if (isfinite(lo)) upd(P.oSL, P.oZL, e, v - lo, dv);
-                if (isfinite(hi)) upd(P.oSU, P.oZU, e, hi - v, -dv);
+            {
+                auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double zl, double su, double zu) {
+                    double s2, z2;
+                    if (isfinite(lo)) { upd(sl, zl, v - lo, dv, s2, z2); wsb[oSL + e] = s2; wsb[oZL + e] = z2; }
+                    if (isfinite(hi)) { upd(su, zu, hi - v, -dv, s2, z2); wsb[oSU + e] = s2; wsb[oZU + e] = z2; }
+                };
+                for (int e0 = lane; e0 < nV; e0 += 128) {
+                    const int e1 = e0 + 64, i1 = e1 < nV ? e1 : e0;
+                    const double v0 = wsb[oV + e0], dv0 = wsb[odV + e0], lo0 = lbS[e0], hi0 = ubS[e0], sl0 = wsb[oSL + e0], zl0 = wsb[oZL + e0], su0 = wsb[oSU + e0],
+                                 zu0 = wsb[oZU + e0];
+                    const double v1 = wsb[oV + i1], dv1 = wsb[odV + i1], lo1 = lbS[i1], hi1 = ubS[i1], sl1 = wsb[oSL + i1], zl1 = wsb[oZL + i1], su1 = wsb[oSU + i1],
+                                 zu1 = wsb[oZU + i1];
+                    item(e0, v0, dv0, lo0, hi0, sl0, zl0, su0, zu0);
+                    if (e1 < nV) item(e1, v1, dv1, lo1, hi1, sl1, zl1, su1, zu1);
+                }
+            }
+            for (int k = 1 + lane; k <= N; k += 64) {
+                // multipliers of the equality rows of stage k: lambda (lambda+ is in SD), eta
+                LV(k, 0) += alpha * (SD[3 * k] - LV(k, 0)); LV(k, 1) += alpha * (SD[3 * k + 1] - LV(k, 1)); LV(k, 2) += alpha * (SD[3 * k + 2] - LV(k, 2));
+#pragma unroll
+                for (int m0 = 0; m0 < RM; m0 += CH)
+                    if (R_ >= 0 || m0 < R) {
+                        double e0[CH], e1[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if (m0 + u < RM) { const int m = M_IX(m0 + u, m0); e0[u] = RV(oeta, k, m); e1[u] = RV(oetan, k, m); }
+#pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if (m0 + u < RM && M_ON(m0 + u)) RV(oeta, k, m0 + u) = e0[u] + alpha * (e1[u] - e0[u]);
+                    }
             }
             for (int o = lane; o < 2 * Nc; o += 64) {
-                const double u = W_(oU, o), du = W_(P.odU, o);
-                upd(P.oSLu, P.oZLu, o, u - lbu[o], du);
-                upd(P.oSUu, P.oZUu, o, ubu[o] - u, -du);
+                const double u = wsb[oU + o], du = wsb[odU + o];
+                double s2, z2;
+                upd(wsb[oSLu + o], wsb[oZLu + o], u - lbu[o], du, s2, z2); wsb[oSLu + o] = s2; wsb[oZLu + o] = z2;
+                upd(wsb[oSUu + o], wsb[oZUu + o], ubu[o] - u, -du, s2, z2); wsb[oSUu + o] = s2; wsb[oZUu + o] = z2;
             }
-            { int64_t t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_; }      // the trial point of the accepted step length is in (oVt, oUt)
-            for (int e = 3 + lane; e < (N + 1) * 3; e += 64) W_(P.olam, e) += alpha * (W_(P.olamn, e) - W_(P.olam, e));
-            for (int e = R + lane; e < (N + 1) * R; e += 64) W_(P.oeta, e) += alpha * (W_(P.oetan, e) - W_(P.oeta, e));
+            { int t_ = oV; oV = oVt; oVt = t_; t_ = oU; oU = oUt; oUt = t_; }      // the trial point of the accepted step length is in (oVt, oUt)
+            f = ft; th0 = tht; e_c = ect;      // ... and its evaluation (objective, residual norms, sin / cos in SB) is the line search's last one
             __syncthreads();
-            f = eval_point(oV, oU, true, th0, e_c);
-            __syncthreads();
+            LP(9);
             it++;
             if (n_tiny >= 5) {
                 if (n_restart >= 3) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); break; } status = NMPC_STATUS_STALLED; break; }
-                n_restart++; n_tiny = 0; mu = fmax(mu, P.mu_init); restarting = true;
+                n_restart++; n_tiny = 0; mu = uni(fmax(mu, P.mu_init)); restarting = true;
                 break;
             }
         }
         if (!restarting) break;
     }
     __syncthreads();
-    for (int e = lane; e < nV; e += 64) wo[e] = W_(oV, e);
-    for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)nV + e] = W_(oU, e);
+    for (int k = lane; k <= N; k += 64) for (int c = 0; c < ns; c++) wo[(size_t)k * ns + c] = SV(oV, k, c);
+    for (int e = lane; e < 2 * Nc; e += 64) wo[(size_t)NP1 * ns + e] = wsb[oU + e];
     if (lane == 0) {
         if (obj_out) obj_out[b] = f;
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = it;
         if (kkt_out) kkt_out[b] = kkt;
     }
+#ifdef NMPC_LIDAR_PROFILE
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < 12; i++) wo[i] = (double)prof[i];
+#endif
 }
+#undef SV
+#undef RV
+#undef LV
+#undef C_ON
+#undef C_IX
+#undef M_ON
+#undef M_IX
 
 // f (V4:135-136) and g = [gx; gd] (V4:151): one wavefront per instance, lane = stage (+64, ...); trip k == N handles the initial rows.
 // The objective is summed in a fixed order (per lane over its stages, then a butterfly over the wave): bit-reproducible from run to run.
@@ -700,7 +935,7 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     if (!h) return NMPC_E_NOMEM;
     if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
     h->cfg = *cfg; h->max_batch = max_batch;
-    h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3);
+    h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3 + 2 * NMPC_LIDAR_MAX_RAYS);
     if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU (N ~ 1000 with Nc = N / 2)
     nmpc_lidar::LParams &P = h->P;
     memset(&P, 0, sizeof(P));
@@ -710,23 +945,34 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     for (int i = 0; i < 2; i++) P.r[i] = cfg->r[i];
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t at = o; o += n; return at; };
-    const int64_t nV = (int64_t)(N + 1) * ns, nU = 2 * Nc, nL = (int64_t)(N + 1) * 3, nE = (int64_t)(N + 1) * R;
-    P.oV = take(nV); P.oU = take(nU); P.olam = take(nL); P.oeta = take(nE); P.oSL = take(nV); P.oZL = take(nV); P.oSU = take(nV); P.oZU = take(nV);
-    P.oSLu = take(nU); P.oZLu = take(nU); P.oSUu = take(nU); P.oZUu = take(nU); P.odV = take(nV); P.odU = take(nU); P.olamn = take(nL); P.oetan = take(nE);
-    P.oVt = take(nV); P.oUt = take(nU); P.osn = take(N); P.ocs = take(N); P.oHxx = take(4 * (int64_t)(N + 1)); P.ogx = take(nL); P.oWd = take(nE); P.ogdv = take(nE);
-    P.ohuu = take(nU); P.ogu = take(nU); P.ohvt = take(N); P.oKg = take(6 * (int64_t)Nc); P.okff = take(nU); P.opo = take(2 * R);
+    const int64_t nV = (int64_t)(N + 1) * ns, nU = 2 * Nc, nL = (int64_t)N * 3, nE = (int64_t)N * R;
+    P.oeta = take(nE); P.oetan = take(nE); P.oWd = take(nE); P.ogdv = take(nE); P.olam = take(nL);
+    P.oU = take(nU); P.oUt = take(nU); P.odU = take(nU); P.oSLu = take(nU); P.oZLu = take(nU); P.oSUu = take(nU); P.oZUu = take(nU);
+    P.oV = take(nV); P.oVt = take(nV); P.odV = take(nV); P.oSL = take(nV); P.oZL = take(nV); P.oSU = take(nV); P.oZU = take(nV);
     P.total = o;
     P.total = (P.total + 15) / 16 * 16;      // every instance starts on a 128-byte boundary
     P.S = max_batch;
     h->ws_bytes = (int64_t)sizeof(double) * P.total * P.S;
     if (hipMalloc((void **)&h->ws, (size_t)h->ws_bytes) != hipSuccess) { free(h); return NMPC_E_NOMEM; }
-    if (hipMalloc((void **)&h->lb, sizeof(double) * nv) != hipSuccess || hipMalloc((void **)&h->ub, sizeof(double) * nv) != hipSuccess) {
-        (void)hipFree(h->ws); if (h->lb) (void)hipFree(h->lb); free(h); return NMPC_E_NOMEM;
-    }
-    if (hipMemcpy(h->lb, lbx, sizeof(double) * nv, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->ub, ubx, sizeof(double) * nv, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(h->ws); (void)hipFree(h->lb); (void)hipFree(h->ub); free(h); return NMPC_E_HIP;
-    }
-    P.lb = h->lb; P.ub = h->ub;
+    // bounds in the solve kernel's layout (LParams): state part component-major with stage 0 opened, controls, then the caller's stage-0 bounds
+    const size_t nb = (size_t)nv + ns;
+    double *hl = (double *)malloc(sizeof(double) * nb), *hu = (double *)malloc(sizeof(double) * nb);
+    if (!hl || !hu) { free(hl); free(hu); (void)hipFree(h->ws); free(h); return NMPC_E_NOMEM; }
+    int n_ineq = 4 * Nc;
+    for (int k = 0; k <= N; k++)
+        for (int c = 0; c < ns; c++) {
+            const double lo = lbx[(size_t)k * ns + c], hi = ubx[(size_t)k * ns + c];
+            hl[(size_t)c * (N + 1) + k] = k ? lo : -INFINITY; hu[(size_t)c * (N + 1) + k] = k ? hi : INFINITY;
+            if (k) n_ineq += (isfinite(lo) ? 1 : 0) + (isfinite(hi) ? 1 : 0);
+            else { hl[(size_t)nv + c] = lo; hu[(size_t)nv + c] = hi; }
+        }
+    for (int e = 0; e < 2 * Nc; e++) { hl[nV + e] = lbx[nV + e]; hu[nV + e] = ubx[nV + e]; }
+    P.n_ineq = n_ineq;
+    bool okb = hipMalloc((void **)&h->lb, sizeof(double) * nb) == hipSuccess && hipMalloc((void **)&h->ub, sizeof(double) * nb) == hipSuccess;
+    okb = okb && hipMemcpy(h->lb, hl, sizeof(double) * nb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(h->ub, hu, sizeof(double) * nb, hipMemcpyHostToDevice) == hipSuccess;
+    free(hl); free(hu);
+    if (!okb) { (void)hipFree(h->ws); if (h->lb) (void)hipFree(h->lb); if (h->ub) (void)hipFree(h->ub); free(h); return NMPC_E_HIP; }
+    P.lb = h->lb; P.ub = h->ub; P.lb0 = h->lb + nv; P.ub0 = h->ub + nv;
     *out = h;
     return NMPC_OK;
 }
@@ -759,11 +1005,12 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     if (!p || !w0 || !w_out) return NMPC_E_ARG;
     LidarDeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    // the dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a handle: set per launch when this handle needs more than HIP's
-    // default of 64 KB (a second handle with another horizon would otherwise change the limit under this one)
-    if (h->lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)nmpc_lidar::lidar_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) return NMPC_E_HIP;
-    hipLaunchKernelGGL(nmpc_lidar::lidar_solve_kernel, dim3((unsigned)B), dim3(64), h->lds_bytes, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
+    // the ray count of the scripts gets its own instantiation (component loops unrolled, loads of a stage issued together); any other count
+    // runs the predicated one.  The dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a handle: set per launch when this
+    // handle needs more than HIP's default of 64 KB (a second handle with another horizon would otherwise change the limit under this one)
+    auto kern = (h->cfg.R == 10) ? nmpc_lidar::lidar_solve_kernel<10> : nmpc_lidar::lidar_solve_kernel<-1>;
+    if (h->lds_bytes > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) return NMPC_E_HIP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), h->lds_bytes, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
