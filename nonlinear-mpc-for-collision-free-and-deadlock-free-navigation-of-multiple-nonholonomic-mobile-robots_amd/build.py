@@ -14,8 +14,10 @@ INFO = os.path.join(LIBDIR, "build_info.json")    # what the last build() call d
 SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_lidar.hip", "nmpc_api.cpp"]
 # per-source code generation switches.  nmpc_lidar.hip: machine-level loop-invariant code motion hoists the 64-bit literals of log() / sincos()
 # out of the stage loops into vector registers, the allocator then spills them and reloads each one from scratch, with a full vmcnt wait, at
-# every use (496 scratch loads in the kernel, 6 per log); without the pass they are re-materialised where used (114)
-FILE_FLAGS = {"nmpc_lidar.hip": os.environ.get("NMPC_LIDAR_FLAGS", "-mllvm -disable-machine-licm").split()}
+# every use (496 scratch loads in the kernel, 6 per log); without the pass they are re-materialised where used (114).  nmpc_solve_col.hip:
+# same pass, measured A/B in one session (round 3): two robots +2.3 %, six +3.7 % (B = 16384: +5.2 %), composite +2.3 %, ten +-0.
+FILE_FLAGS = {"nmpc_lidar.hip": os.environ.get("NMPC_LIDAR_FLAGS", "-mllvm -disable-machine-licm").split(),
+              "nmpc_solve_col.hip": os.environ.get("NMPC_COL_FLAGS", "-mllvm -disable-machine-licm").split()}
 DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h"] + [os.path.join("..", "..", "include", h) for h in ("nmpc.h", "nmpc_lidar.h", "nmpc_constants.h", "nmpc_debug.h")]
 
 
@@ -34,8 +36,9 @@ def source_hash() -> str:
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode()); h.update(f.read())
-    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS", "NMPC_LIDAR_FLAGS"):
+    for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
         h.update((k + "=" + os.environ.get(k, "")).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())      # per-source code generation switches (defaults and their overrides)
     return h.hexdigest()[:16]
 
 

@@ -329,8 +329,9 @@ def _col_kernel_asm(tmp_path, m):
     d = tmp_path / ("m%d" % m)
     d.mkdir()
     src = os.path.join(bld.CSRC, "nmpc_solve_col.hip")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="t"', "-DNMPC_COL_ONLY_M=%d" % m,
-                           "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", str(d / "col.o"), "--save-temps=obj"], cwd=bld.CSRC)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="t"', "-DNMPC_COL_ONLY_M=%d" % m]
+                          + bld.FILE_FLAGS.get("nmpc_solve_col.hip", [])          # the code generation switches of the shipped build
+                          + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", str(d / "col.o"), "--save-temps=obj"], cwd=bld.CSRC)
     return str(d / "nmpc_solve_col-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
