@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     double *SB = lsm;                              // [N+1][13]  Hxx(4) gx(3) hvt sin cos pose(3)
     double *SC = SB + (size_t)NP1 * 13;            // [Nc][16]   u(2) huu(2) gu(2) K(6) kff(2) du(2)
     double *SD = SC + (size_t)Nc * 16;             // [N+1][3]   pose step; the adjoint recursion overwrites it with lambda+
-    double *SP = SD + (size_t)NP1 * 3;             // [R][2]     lidar points of stage 0
+    double *SP = SD + (size_t)NP1 * 3;             // [R][2]     lidar points of stage 0 (16 ray slots)
+    double *SF = SP + 2 * NMPC_LIDAR_MAX_RAYS;     // [N][12]    stage maps of the forward recursion, then the stage terms of the adjoint one
     const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
     double *wo = w_out + (size_t)b * P.nvar;
     const double *lbS = P.lb, *ubS = P.ub, *lbu = P.lb + (size_t)NP1 * ns, *ubu = P.ub + (size_t)NP1 * ns;      // component-major, stage 0 = -+inf
@@ -525,67 +526,104 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             __syncthreads();
 
             LP(3);
-            // ---- C. forward sweep: the pose recursion uniform on all lanes (operands and results in LDS), then one stage per lane: the pose
-            //      step to the workspace, the R distance states of the stage and the multipliers eta+ of their rows
+            // ---- C. forward sweep.  The closed-loop maps of the stages are formed in parallel (one stage per lane): with the gains of the sweep,
+            //      dx+ = (A + B K) dx + (B kff - c) below the control horizon and dx+ = A dx + (B du_held - c) above it, so that the recursion
+            //      over the horizon — uniform on all lanes, operands and results in LDS — is three dependent multiply-adds per stage
+            for (int k = lane; k < N; k += 64) {
+                const double *sb = SB + k * 13, *sc = SC + cof(k) * 16;
+                double *sf = SF + k * 12;
+                const double u0 = sc[0], u1 = sc[1], sn = sb[8], cs = sb[9];
+                const double a = -T * u0 * sn, bq = T * u0 * cs, Tc = T * cs, Ts = T * sn;
+                const double c0 = sb[13 + 10] - (sb[10] + T * u0 * cs), c1 = sb[13 + 11] - (sb[11] + T * u0 * sn), c2 = sb[13 + 12] - (sb[12] + T * u1);
+                if (k <= Nc - 1) {
+                    const double K00 = sc[6], K01 = sc[7], K02 = sc[8], K10 = sc[9], K11 = sc[10], K12 = sc[11], kf0 = sc[12], kf1 = sc[13];
+                    sf[0] = 1.0 + Tc * K00; sf[1] = Tc * K01; sf[2] = a + Tc * K02;
+                    sf[3] = Ts * K00; sf[4] = 1.0 + Ts * K01; sf[5] = bq + Ts * K02;
+                    sf[6] = T * K10; sf[7] = T * K11; sf[8] = 1.0 + T * K12;
+                    sf[9] = Tc * kf0 - c0; sf[10] = Ts * kf0 - c1; sf[11] = T * kf1 - c2;
+                } else { sf[0] = a; sf[1] = bq; sf[2] = Tc; sf[3] = Ts; sf[4] = c0; sf[5] = c1; sf[6] = c2; }
+            }
+            __syncthreads();
             {
-                // Stages in batches of NMPC_LIDAR_UNROLL: the LDS operands of a batch are read FIRST (the compiler does not move LDS reads across
-                // the lane-0 stores of the previous stages — one exposed LDS round trip per stage otherwise, ten times the arithmetic), then the
-                // stages are walked, then their results are stored.  Same arithmetic, stage by stage, as the plain loop.
+                // stages in batches: the LDS operands of a batch are read FIRST (the compiler does not move LDS reads across the lane-0 stores of
+                // the previous stages — one exposed LDS round trip per stage otherwise), then the stages are walked, then the results stored
                 constexpr int UB = NMPC_LIDAR_UNROLL;
-                double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0, du0 = 0.0, du1 = 0.0;
+                double dx0 = 0.0, dx1 = 0.0, dx2 = 0.0;
                 if (lane == 0) { SD[0] = 0.0; SD[1] = 0.0; SD[2] = 0.0; }
-                for (int k0 = 0; k0 < N; k0 += UB) {
-                    double s_[UB], c_[UB], px[UB + 1], py[UB + 1], pt[UB + 1], u0_[UB], u1_[UB], K_[UB][6], kf[UB][2], n_[UB][3], du_[UB][2];
-#pragma unroll
-                    for (int i = 0; i <= UB; i++) {
-                        const double *sb = SB + (k0 + i <= N ? k0 + i : N) * 13;
-                        px[i] = sb[10]; py[i] = sb[11]; pt[i] = sb[12];
-                        if (i < UB) { s_[i] = sb[8]; c_[i] = sb[9]; }
-                    }
+                for (int k0 = 0; k0 < Nc; k0 += UB) {
+                    double F_[UB][12], n_[UB][3];
 #pragma unroll
                     for (int i = 0; i < UB; i++) {
-                        const double *sc = SC + cof(k0 + i < N ? k0 + i : N - 1) * 16;
-                        u0_[i] = sc[0]; u1_[i] = sc[1]; kf[i][0] = sc[12]; kf[i][1] = sc[13];
+                        const double *sf = SF + (k0 + i < Nc ? k0 + i : Nc - 1) * 12;
 #pragma unroll
-                        for (int q_ = 0; q_ < 6; q_++) K_[i][q_] = sc[6 + q_];
+                        for (int q_ = 0; q_ < 12; q_++) F_[i][q_] = sf[q_];
                     }
 #pragma unroll
-                    for (int i = 0; i < UB; i++) {
-                        const int k = k0 + i;
-                        if (k < N) {
-                            if (k <= Nc - 1) {
-                                du0 = kf[i][0] + K_[i][0] * dx0 + K_[i][1] * dx1 + K_[i][2] * dx2;
-                                du1 = kf[i][1] + K_[i][3] * dx0 + K_[i][4] * dx1 + K_[i][5] * dx2;
-                            }
-                            const double u0 = u0_[i], u1 = u1_[i], s = s_[i], c = c_[i];
-                            const double n0 = dx0 + (-T * u0 * s) * dx2 + T * c * du0 - (px[i + 1] - (px[i] + T * u0 * c));
-                            const double n1 = dx1 + (T * u0 * c) * dx2 + T * s * du0 - (py[i + 1] - (py[i] + T * u0 * s));
-                            const double n2 = dx2 + T * du1 - (pt[i + 1] - (pt[i] + T * u1));
+                    for (int i = 0; i < UB; i++)
+                        if (k0 + i < Nc) {
+                            const double n0 = F_[i][9] + F_[i][0] * dx0 + F_[i][1] * dx1 + F_[i][2] * dx2, n1 = F_[i][10] + F_[i][3] * dx0 + F_[i][4] * dx1 + F_[i][5] * dx2,
+                                         n2 = F_[i][11] + F_[i][6] * dx0 + F_[i][7] * dx1 + F_[i][8] * dx2;
                             dx0 = n0; dx1 = n1; dx2 = n2;
-                            n_[i][0] = n0; n_[i][1] = n1; n_[i][2] = n2; du_[i][0] = du0; du_[i][1] = du1;
+                            n_[i][0] = n0; n_[i][1] = n1; n_[i][2] = n2;
                         }
-                    }
                     if (lane == 0) {
 #pragma unroll
+                        for (int i = 0; i < UB; i++)
+                            if (k0 + i < Nc) { SD[3 * (k0 + i + 1)] = n_[i][0]; SD[3 * (k0 + i + 1) + 1] = n_[i][1]; SD[3 * (k0 + i + 1) + 2] = n_[i][2]; }
+                    }
+                }
+                if (Nc < N) {      // the held control: the one of stage Nc - 1, from the pose step that stage started from
+                    const double *sc = SC + (Nc - 1) * 16, *sd = SD + 3 * (Nc - 1);
+                    const double du0 = sc[12] + sc[6] * sd[0] + sc[7] * sd[1] + sc[8] * sd[2], du1 = sc[13] + sc[9] * sd[0] + sc[10] * sd[1] + sc[11] * sd[2];
+                    for (int k0 = Nc; k0 < N; k0 += UB) {
+                        double F_[UB][7], n_[UB][3];
+#pragma unroll
                         for (int i = 0; i < UB; i++) {
-                            const int k = k0 + i;
-                            if (k < N) {
-                                if (k <= Nc - 1) { SC[k * 16 + 14] = du_[i][0]; SC[k * 16 + 15] = du_[i][1]; }
-                                SD[3 * (k + 1)] = n_[i][0]; SD[3 * (k + 1) + 1] = n_[i][1]; SD[3 * (k + 1) + 2] = n_[i][2];
+                            const double *sf = SF + (k0 + i < N ? k0 + i : N - 1) * 12;
+#pragma unroll
+                            for (int q_ = 0; q_ < 7; q_++) F_[i][q_] = sf[q_];
+                        }
+#pragma unroll
+                        for (int i = 0; i < UB; i++)
+                            if (k0 + i < N) {
+                                const double n0 = dx0 + F_[i][0] * dx2 + (F_[i][2] * du0 - F_[i][4]), n1 = dx1 + F_[i][1] * dx2 + (F_[i][3] * du0 - F_[i][5]),
+                                             n2 = dx2 + (T * du1 - F_[i][6]);
+                                dx0 = n0; dx1 = n1; dx2 = n2;
+                                n_[i][0] = n0; n_[i][1] = n1; n_[i][2] = n2;
                             }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < UB; i++)
+                                if (k0 + i < N) { SD[3 * (k0 + i + 1)] = n_[i][0]; SD[3 * (k0 + i + 1) + 1] = n_[i][1]; SD[3 * (k0 + i + 1) + 2] = n_[i][2]; }
                         }
                     }
                 }
             }
             __syncthreads();
+            // control steps du_j = kff_j + K_j dx_j (one control per lane): to the workspace and, for the adjoint recursion, to LDS
+            for (int j = lane; j < Nc; j += 64) {
+                double *sc = SC + j * 16;
+                const double *sd = SD + 3 * j;
+                const double du0 = sc[12] + sc[6] * sd[0] + sc[7] * sd[1] + sc[8] * sd[2], du1 = sc[13] + sc[9] * sd[0] + sc[10] * sd[1] + sc[11] * sd[2];
+                sc[14] = du0; sc[15] = du1;
+                wsb[odU + 2 * j] = du0; wsb[odU + 2 * j + 1] = du1;
+            }
+            __syncthreads();
             LP(4);
             double mult_max = 0.0;
-            for (int o = lane; o < 2 * Nc; o += 64) wsb[odU + o] = SC[(o >> 1) * 16 + 14 + (o & 1)];
             double dphi_f = 0.0;      // directional derivative of the objective (states; the controls' part is added in D)
             for (int k = 1 + lane; k <= N; k += 64) {      // dd = G dx + (g - d);  eta+ = -(gd + Wd dd)
                 const double d0 = SD[3 * k], d1 = SD[3 * k + 1], d2 = SD[3 * k + 2], x = SB[k * 13 + 10], y = SB[k * 13 + 11];
                 SV(odV, k, 0) = d0; SV(odV, k, 1) = d1; SV(odV, k, 2) = d2;
                 if (k < N) { dphi_f += 2 * q0 * (x - xs0) * d0; dphi_f += 2 * q1 * (y - xs1) * d1; dphi_f += 2 * q2 * (SB[k * 13 + 12] - xs2) * d2; }
+                {   // the adjoint recursion lambda_k = r_k + A_k' lambda_k+1: its stage terms r_k = -(g + H dx) - (0, 0, hvt du0) and the two entries of A_k
+                    const double *sb = SB + k * 13;
+                    double *sf = SF + (k - 1) * 12;
+                    const double H0 = sb[0], H1 = sb[1], H2 = sb[2], H3 = sb[3];
+                    double r2 = -(sb[6] + H3 * d2), aa = 0.0, bb = 0.0;
+                    if (k < N) { const double *sc = SC + cof(k) * 16; const double u0 = sc[0]; r2 -= sb[7] * sc[14]; aa = -T * u0 * sb[8]; bb = T * u0 * sb[9]; }
+                    sf[0] = -(sb[4] + H0 * d0 + H1 * d1); sf[1] = -(sb[5] + H1 * d0 + H2 * d1); sf[2] = r2; sf[3] = aa; sf[4] = bb;
+                }
 #pragma unroll
                 for (int m0 = 0; m0 < RM; m0 += CH)
                     if (R_ >= 0 || m0 < R) {
@@ -613,39 +651,25 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                 constexpr int UB = NMPC_LIDAR_UNROLL;      // batches as in the forward recursion: operands first, then the stages, then the stores
                 double ln0 = 0.0, ln1 = 0.0, ln2 = 0.0;
                 for (int k0 = N; k0 >= 1; k0 -= UB) {
-                    double h_[UB][10], d_[UB][3], u0_[UB], du0_[UB], l_[UB][3];
+                    double F_[UB][5], l_[UB][3];
 #pragma unroll
                     for (int i = 0; i < UB; i++) {
-                        const int k = k0 - i >= 1 ? k0 - i : 1;
-                        const double *sb = SB + k * 13, *sc = SC + cof(k < N ? k : N - 1) * 16;
+                        const double *sf = SF + ((k0 - i >= 1 ? k0 - i : 1) - 1) * 12;
 #pragma unroll
-                        for (int q_ = 0; q_ < 10; q_++) h_[i][q_] = sb[q_];
-                        d_[i][0] = SD[3 * k]; d_[i][1] = SD[3 * k + 1]; d_[i][2] = SD[3 * k + 2];
-                        u0_[i] = sc[0]; du0_[i] = sc[14];
+                        for (int q_ = 0; q_ < 5; q_++) F_[i][q_] = sf[q_];
                     }
 #pragma unroll
-                    for (int i = 0; i < UB; i++) {
-                        const int k = k0 - i;
-                        if (k >= 1) {
-                            const double dx0 = d_[i][0], dx1 = d_[i][1], dx2 = d_[i][2];
-                            const double H0 = h_[i][0], H1 = h_[i][1], H2 = h_[i][2], H3 = h_[i][3];
-                            double l0 = -(h_[i][4] + H0 * dx0 + H1 * dx1), l1 = -(h_[i][5] + H1 * dx0 + H2 * dx1), l2 = -(h_[i][6] + H3 * dx2);
-                            if (k < N) {
-                                const double u0 = u0_[i];
-                                l0 += ln0; l1 += ln1;
-                                l2 += ln2 + (-T * u0 * h_[i][8]) * ln0 + (T * u0 * h_[i][9]) * ln1 - h_[i][7] * du0_[i];
-                            }
+                    for (int i = 0; i < UB; i++)
+                        if (k0 - i >= 1) {       // (a, bq are zero at k = N and lambda_N+1 = 0)
+                            const double l0 = F_[i][0] + ln0, l1 = F_[i][1] + ln1, l2 = F_[i][2] + ln2 + F_[i][3] * ln0 + F_[i][4] * ln1;
                             ln0 = l0; ln1 = l1; ln2 = l2;
                             l_[i][0] = l0; l_[i][1] = l1; l_[i][2] = l2;
                             mult_max = fmax(mult_max, fmax(fabs(l0), fmax(fabs(l1), fabs(l2))));
                         }
-                    }
                     if (lane == 0) {
 #pragma unroll
-                        for (int i = 0; i < UB; i++) {
-                            const int k = k0 - i;
-                            if (k >= 1) { SD[3 * k] = l_[i][0]; SD[3 * k + 1] = l_[i][1]; SD[3 * k + 2] = l_[i][2]; }
-                        }
+                        for (int i = 0; i < UB; i++)
+                            if (k0 - i >= 1) { SD[3 * (k0 - i)] = l_[i][0]; SD[3 * (k0 - i) + 1] = l_[i][1]; SD[3 * (k0 - i) + 2] = l_[i][2]; }
                     }
                 }
                 mult_max = wmax_(mult_max);
@@ -935,7 +959,7 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     if (!h) return NMPC_E_NOMEM;
     if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
     h->cfg = *cfg; h->max_batch = max_batch;
-    h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3 + 2 * NMPC_LIDAR_MAX_RAYS);
+    h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3 + 2 * NMPC_LIDAR_MAX_RAYS + (size_t)N * 12);
     if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU (N ~ 1000 with Nc = N / 2)
     nmpc_lidar::LParams &P = h->P;
     memset(&P, 0, sizeof(P));

@@ -45,7 +45,10 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #define NMPC_COL_DPP 1
 #endif
 #ifndef NMPC_COL_WAVES_SMALL
-#define NMPC_COL_WAVES_SMALL 2      // resident waves per SIMD the register budget of up to three robots is set for (3: 168 VGPRs; measured below)
+#define NMPC_COL_WAVES_SMALL 1      // occupancy the compiler is ASKED for, up to three robots (see col_min_waves; two robots: 1 -> +1.3 % over 2, 3 = 168 VGPRs was slower)
+#endif
+#ifndef NMPC_COL_WAVES_MID
+#define NMPC_COL_WAVES_MID 1        // occupancy the compiler is ASKED for, four to six robots (see col_min_waves)
 #endif
 #ifndef NMPC_COL_RP
 #define NMPC_COL_RP 1        // row-paired backward sweep for two to six robots (see the sweep); 0 keeps one row per register (A/B)
@@ -59,6 +62,15 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 constexpr int rp_slot(int j) { return 2 * ((j >> 1) >> 1) + (j & 1); }
 constexpr int rp_half(int j) { return (j >> 1) & 1; }
 constexpr bool rp_live(int i, int jj, int nc, int nu) { return i >= nc || (4 * (i >> 1) + (i & 1) > jj) || (4 * (i >> 1) + 2 + (i & 1) > jj && 4 * (i >> 1) + 2 + (i & 1) < nu); }
+
+// Second argument of __launch_bounds__.  Two waves per SIMD (8 instances per CU) is what runs for up to six robots either way: asked for 1, the
+// allocator lands on 230..254 registers WITHOUT a spill and the hardware still places two waves; asked for 2 it stops at 256 and spills 56..64
+// dwords to scratch (reloaded at the phase boundaries of every iteration).  Measured A/B in one session, six robots: B = 2048 +3.5 %, 4096
+// +2.5 %, 16384 +3 %.  The one variant that lands above 256 when asked for 1 (four robots, heading bounds, slacks in the workspace: 257) keeps 2.
+constexpr int col_min_waves(int m, int thb, int dl)
+{
+    return m > 6 ? 1 : (m <= 3 ? NMPC_COL_WAVES_SMALL : ((m == 4 && thb && !dl) ? 2 : NMPC_COL_WAVES_MID));
+}
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int N_> __device__ __forceinline__ void fmac_rowb(double &acc, double u, double nr)      // acc += u[lane N_ of my row of 16] * nr
@@ -88,7 +100,7 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
 // wave's iteration for six robots) and waits at a barrier while wave 0 runs the two sweeps; for batches whose launch is as long as their
 // longest solve.
 template <int M_, int THB, int DL, int TPBK = 64>
-__global__ __launch_bounds__(TPBK, (M_ <= 3 ? NMPC_COL_WAVES_SMALL : (M_ <= 6 ? 2 : 1))) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
+__global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_kernel(const KParams P, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                         double *__restrict__ w_out, double *__restrict__ obj_out,
                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
                                                         double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
