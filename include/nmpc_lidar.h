@@ -47,7 +47,7 @@ int32_t nmpc_lidar_n_p(const nmpc_lidar_config_t *cfg);   /* 6 + 2R             
 
 /* Replaces nlpsol(...) of V4:156-157.  lbx / ubx: HOST arrays of n_var entries (args['lbx'], args['ubx'] of V4:174-176).
  * NMPC_E_ARG also when the per-stage operands of the horizon recursions exceed the LDS of a compute unit:
- * 8 (16 (N+1) + 16 Nc) bytes <= 160 KB, i.e. N up to ~850 with Nc = N/2 (the scripts use N = 100 / 125). */
+ * 8 (16 (N+1) + 16 Nc + 12 N + 32) bytes <= 160 KB, i.e. N up to ~560 with Nc = N/2 (the scripts use N = 100 / 125). */
 int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, const double *ubx, int32_t max_batch, nmpc_lidar_handle_t **out);
 int32_t nmpc_lidar_destroy(nmpc_lidar_handle_t *h);
 

@@ -65,6 +65,31 @@ struct LogSum {
     }
 };
 
+// reciprocal: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; five dependent operations where the IEEE division chain has eleven — the
+// Riccati stage of a lone wavefront is one long dependency chain with two pivots in it)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+#ifndef NMPC_LIDAR_DPP
+#define NMPC_LIDAR_DPP 1        // 1: column-per-lane Riccati stage (DPP broadcasts); 0: every lane walks the upper triangle (A/B)
+#endif
+// acc += acc[lane L_ of my row of 16 lanes] * nr — a column operation of the column-per-lane Riccati stage.  The s_nop gives the two wait states a DPP
+// read needs after a VALU write of its source register whatever the compiler placed in front of the statement (its hazard recognizer does not
+// look into inline assembly).
+template <int L_> __device__ __forceinline__ void dpp_fmac(double &acc, double nr)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(nr), "n"(L_));
+}
+template <int L_> __device__ __forceinline__ void dpp_fmac2(double &acc, double u, double nr)      // acc += u[lane L_ of my row] * nr
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(nr), "n"(L_));
+}
+
 // wave reductions whose result the compiler knows to be uniform (scalar control flow)
 __device__ __forceinline__ double uni(double v)
 {
@@ -440,6 +465,86 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             bool ok;
             for (;;) {
                 ok = true;
+#if NMPC_LIDAR_DPP
+                // Column per lane: lane q of every row of 16 lanes owns column q of the 5 x 5 cost-to-go matrix (q = 0..2 pose, 3..4 held control) and
+                // lane 5 the linear term; its five rows are the registers m0..m4.  With At = [[A, B], [0, I]] the product P At is a combination
+                // of columns — v_fmac_f64_dpp row_newbcast of the source column with a per-lane coefficient (the defect correction p - P c of
+                // the linear term is one more coefficient of the same three instructions per row) —, At' (P At) a combination of rows, i.e. of
+                // registers with uniform coefficients; the two control pivots are eliminated like in the swarm kernel (multiplier column by
+                // DPP broadcast, normalised pivot row per lane).  ~150 instructions per stage for all entries at once, against ~260 when every
+                // lane walks the 15 entries of the upper triangle by itself.
+                const int q16 = lane & 15;
+                const double i0_ = q16 == 0 ? 1.0 : 0.0, i1_ = q16 == 1 ? 1.0 : 0.0, i2_ = q16 == 2 ? 1.0 : 0.0, i3_ = q16 == 3 ? 1.0 : 0.0, i4_ = q16 == 4 ? 1.0 : 0.0,
+                             i5_ = q16 == 5 ? 1.0 : 0.0;
+                const bool isctl = q16 == 3 || q16 == 4, stor = lane < 16 && (q16 < 3 || q16 == 5);
+                const int ko0 = q16 < 3 ? 6 + q16 : 12, ko1 = q16 < 3 ? 9 + q16 : 13;
+                double m0, m1, m2, m3 = 0.0, m4 = 0.0;
+                {
+                    const double *sb = SB + N * 13;
+                    m0 = sb[0] * i0_ + sb[1] * i1_ + sb[4] * i5_; m1 = sb[1] * i0_ + sb[2] * i1_ + sb[5] * i5_; m2 = sb[3] * i2_ + sb[6] * i5_;
+                }
+                auto fetch = [&](int k, double *o_, double *on_, double *oc_) {
+                    const double *sb = SB + k * 13, *sc = SC + cof(k) * 16;
+#pragma unroll
+                    for (int q_ = 0; q_ < 13; q_++) o_[q_] = sb[q_];
+                    on_[0] = sb[13 + 10]; on_[1] = sb[13 + 11]; on_[2] = sb[13 + 12];
+#pragma unroll
+                    for (int q_ = 0; q_ < 6; q_++) oc_[q_] = sc[q_];
+                };
+                auto lane_val = [&](double v, int l) {      // v of lane l, as a wave-uniform value
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+                };
+                auto stage = [&](int k, const double *o_, const double *on_, const double *oc_) -> bool {
+                    const int j = cof(k);
+                    const double H0 = o_[0], H1 = o_[1], H2 = o_[2], H3 = o_[3], g0 = o_[4], g1 = o_[5], g2 = o_[6], hv = o_[7], s = o_[8], c = o_[9];
+                    const double u0 = oc_[0], u1 = oc_[1], huu0 = oc_[2], huu1 = oc_[3], gu0 = oc_[4], gu1 = oc_[5];
+                    const double a = -T * u0 * s, bq = T * u0 * c, Tc = T * c, Ts = T * s;
+                    const double cd0 = on_[0] - (o_[10] + T * u0 * c), cd1 = on_[1] - (o_[11] + T * u0 * s), cd2 = on_[2] - (o_[12] + T * u1);
+                    // columns: col2 += a col0 + bq col1, col3 += Tc col0 + Ts col1, col4 += T col2, linear term -= c0 col0 + c1 col1 + c2 col2
+                    // (column 2 is a source before it is a target; columns 0 and 1 never change)
+                    const double cf2 = T * i4_ - cd2 * i5_, cf0 = a * i2_ + Tc * i3_ - cd0 * i5_, cf1 = bq * i2_ + Ts * i3_ - cd1 * i5_;
+                    dpp_fmac<2>(m0, cf2); dpp_fmac<2>(m1, cf2); dpp_fmac<2>(m2, cf2); dpp_fmac<2>(m3, cf2); dpp_fmac<2>(m4, cf2);
+                    dpp_fmac<0>(m0, cf0); dpp_fmac<0>(m1, cf0); dpp_fmac<0>(m2, cf0); dpp_fmac<0>(m3, cf0); dpp_fmac<0>(m4, cf0);
+                    dpp_fmac<1>(m0, cf1); dpp_fmac<1>(m1, cf1); dpp_fmac<1>(m2, cf1); dpp_fmac<1>(m3, cf1); dpp_fmac<1>(m4, cf1);
+                    // rows: row4 += T row2 (the old row 2), row2 += a row0 + bq row1, row3 += Tc row0 + Ts row1
+                    m4 = fma(T, m2, m4);
+                    m2 = fma(a, m0, fma(bq, m1, m2));
+                    m3 = fma(Tc, m0, fma(Ts, m1, m3));
+                    if (k >= 1) {
+                        m0 = fma(H0, i0_, fma(H1, i1_, fma(g0, i5_, m0)));
+                        m1 = fma(H1, i0_, fma(H2, i1_, fma(g1, i5_, m1)));
+                        m2 = fma(H3, i2_, fma(g2, i5_, m2));
+                    }
+                    m2 = fma(hv, i3_, m2); m3 = fma(hv, i2_, m3);
+                    if (k <= Nc - 1) {        // the stage where control j is decided carries its whole diagonal / gradient
+                        m3 = fma(huu0 + delta, i3_, fma(gu0, i5_, m3));
+                        m4 = fma(huu1 + delta, i4_, fma(gu1, i5_, m4));
+                        const double dv = lane_val(m3, 3), d1o = lane_val(m4, 4);
+                        if (!(dv > 0.0)) return false;
+                        const double rdv = rcp_nr(dv);
+                        const double t3 = m3 * rdv, nt3 = -t3;        // pivot row 3 / pivot, per column
+                        dpp_fmac<3>(m0, nt3); dpp_fmac<3>(m1, nt3); dpp_fmac<3>(m2, nt3); dpp_fmac<3>(m4, nt3);
+                        const double d1 = lane_val(m4, 4);
+                        if (!(d1 > 1e-9 * fabs(d1o)) || !(d1 > 0.0)) return false;
+                        const double rd1 = rcp_nr(d1);
+                        const double t4 = m4 * rd1, nt4 = -t4;
+                        dpp_fmac<4>(m0, nt4); dpp_fmac<4>(m1, nt4); dpp_fmac<4>(m2, nt4);
+                        // gains [K | kff] (columns 0..2 | column 5): second control -t4, first -(t3 - (M34 / d3) t4), M34 / d3 = t3 of column 4
+                        double k0v = nt3;
+                        dpp_fmac2<4>(k0v, t3, t4);
+                        if (stor) { SC[j * 16 + ko0] = k0v; SC[j * 16 + ko1] = nt4; }
+                        m3 = 0.0; m4 = 0.0;
+                        if (isctl) { m0 = 0.0; m1 = 0.0; m2 = 0.0; }
+                    }
+                    return true;
+                };
+                for (int k0 = N - 1; k0 >= 0; k0 -= 2) {
+                    double oa[13], na[3], ca[6], ob[13], nb[3], cb[6];
+                    fetch(k0, oa, na, ca); fetch(k0 >= 1 ? k0 - 1 : 0, ob, nb, cb);
+                    if (!stage(k0, oa, na, ca)) { ok = false; break; }
+                    if (k0 >= 1 && !stage(k0 - 1, ob, nb, cb)) { ok = false; break; }
+                }
+#else
                 // Cost-to-go z' P z + 2 p' z kept as the 15 entries of its upper triangle: with At = [[A, B], [0, I]] (A = I + (a, bq) in column
                 // theta, B = [[T c, 0], [T s, 0], [0, T]]) the columns w_j = P At e_j and then M = At' P At are formed for j >= i only — 30
                 // multiply-adds instead of the 50 + 20 of the full product followed by a symmetrisation.
@@ -513,6 +618,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                     if (!stage(k0, oa, na, ca)) { ok = false; break; }
                     if (k0 >= 1 && !stage(k0 - 1, ob, nb, cb)) { ok = false; break; }
                 }
+#endif
                 if (ok) break;
                 ntry++;
                 if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
