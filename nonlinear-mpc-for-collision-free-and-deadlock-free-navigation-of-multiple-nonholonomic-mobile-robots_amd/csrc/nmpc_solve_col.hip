@@ -256,7 +256,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     // ---- merit pieces at (X + a DX, U + a DU, S + a DS): objective, sum log s, l1 infeasibility, max defect / slack residual.
     //      a == 0 evaluates the current point.  Every inequality row carries an explicit slack.
     auto merit = [&](double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
-        double fs = 0.0, l = 0.0, t = 0.0, mc = 0.0, mh = 0.0;
+        double fs = 0.0, t = 0.0, mc = 0.0, mh = 0.0;
+        LogSum ls;      // sum of log(slack): mantissa product and exponent sum per lane, ONE logarithm per wavefront at the end (nmpc_solve_common.h)
         // one bound row: current slack sv, current value h0, step of the value jd, trial value ht
         // (the slacks of one (stage, robot) item enter the barrier as ONE logarithm of their product — 8 to 10 factors between 1e-12
         // and 2 xy_max, far from over/underflow: fp64 log is ~80 instructions, the item would otherwise spend most of its time there)
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             // state bounds of stage k+1
             pr *= ((n0 + P.xymax) * (P.xymax - n0)) * ((n1 + P.xymax) * (P.xymax - n1));
             if (THB) pr *= (n2 + P.thmax) * (P.thmax - n2);
-            l += log(pr);
+            ls.add(pr);
             pr = 1.0;
         }
         for (int it = tid; it < (N - 1) * NPA; it += TPB) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1];
                 sv += a * ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             }
-            l += log(sv);
+            ls.add(sv);
             double r = fabs(h - sv);
             t += r; mh = fmax(mh, r);
         }
@@ -314,11 +315,11 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey);
                 sv += a * ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             }
-            l += log(sv);
+            ls.add(sv);
             double r = fabs(h - sv);
             t += r; mh = fmax(mh, r);
         }
-        fv = wsum<TPB>(fs, RED); lg = wsum<TPB>(l, RED); th = wsum<TPB>(t, RED);
+        fv = wsum<TPB>(fs, RED); lg = wlogsum<TPB>(ls, RED); th = wsum<TPB>(t, RED);
         ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
     };
 

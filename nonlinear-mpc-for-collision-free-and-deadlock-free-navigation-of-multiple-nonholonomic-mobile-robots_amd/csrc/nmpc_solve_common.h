@@ -140,6 +140,41 @@ template <int TPB> __device__ __forceinline__ double wmax(double v, double *red)
 }
 template <int TPB> __device__ __forceinline__ double wmin(double v, double *red) { return -wmax<TPB>(-v, red); }
 
+// Sum of log(s_i), s_i > 0, accumulated as (product of the mantissas, sum of the exponents): four instructions per term instead of a
+// logarithm (~90), one logarithm per wavefront at the end.  The mantissa product is renormalised after every term (no underflow however
+// many terms); a term <= 0 or NaN makes the result NaN, as the logarithm would.
+struct LogSum {
+    double m = 1.0, lo = INFINITY;
+    int e = 0;
+    __device__ __forceinline__ void add(double s_)
+    {
+        const double t = m * __builtin_amdgcn_frexp_mant(s_);
+        e += __builtin_amdgcn_frexp_exp(s_) + __builtin_amdgcn_frexp_exp(t);
+        m = __builtin_amdgcn_frexp_mant(t);
+        lo = fmin(lo, s_);
+    }
+};
+template <int TPB> __device__ __forceinline__ double wlogsum(LogSum a, double *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = a.m * __shfl_xor(a.m, o);
+        a.e += __shfl_xor(a.e, o) + __builtin_amdgcn_frexp_exp(t);
+        a.m = __builtin_amdgcn_frexp_mant(t);
+        a.lo = fmin(a.lo, __shfl_xor(a.lo, o));
+    }
+    double v = (a.lo > 0.0) ? fma((double)a.e, 0.693147180559945309417, log(a.m)) : NAN;
+    if constexpr (TPB > 64) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; w++) t += red[w];
+        v = t;
+    }
+    return uniform_f64(v);
+}
+
 #ifdef NMPC_PROFILE
 #define PROF_T(i)                                                                                                                 \
     do {                                                                                                                          \
