@@ -6,12 +6,14 @@
 //
 // Mapping.  This NLP has ONE robot: the pose block is 3 x 3, the control block 2 x 2, and the R distance states of a stage are
 // eliminated through their own linearised equality rows (d = ||p - pObs||_1), so the Newton system is a 3-state Riccati
-// recursion whose matrices (5 x 5 with the held control of the move-blocked stages) fit the registers of one lane.  One
-// WAVEFRONT solves one instance: the phases that are parallel over the horizon (evaluation, optimality error, condensed stage
-// blocks, step lengths, merit function, update: ~95 % of the memory accesses) give every lane its own stages of the instance's
+// recursion on 5 x 5 matrices (the held control of the move-blocked stages rides along as two states).  One WAVEFRONT solves one
+// instance: the phases that are parallel over the horizon (evaluation, optimality error, condensed stage blocks, step lengths,
+// merit function, update: ~95 % of the memory accesses) give every lane its own stages / variables of the instance's
 // component-major workspace in HBM/L2 (lane-adjacent addresses, wave reductions with v_readfirstlane so that every decision is a
-// scalar branch), and the two recursions over the horizon run uniformly on all lanes out of LDS with lane 0 storing.  (A first version gave every
-// LANE its own instance: 64 serial solves per wavefront whose every access waited on HBM, 0.5 k solves/s — slower than the CPU.)
+// scalar branch); the Riccati recursion keeps one COLUMN of the 5 x 5 matrix per lane (DPP broadcasts, as the swarm kernel does
+// for its 30 x 30 stage), the forward and adjoint recursions run uniformly on all lanes, out of LDS, on stage maps formed in
+// parallel.  DESIGN.md 4.5 has the measurements behind each of these choices.  (A first version gave every LANE its own instance:
+// 64 serial solves per wavefront whose every access waited on HBM, 0.5 k solves/s — slower than the CPU.)
 // Algorithm: the interior-point iteration of nmpc_kernels.hip / the oracle (barrier rule, fraction to the boundary, non-monotone
 // l1-merit search, inertia shift on the control diagonal, barrier restart).
 #include <hip/hip_runtime.h>
@@ -130,16 +132,6 @@ __device__ __forceinline__ double wlogsum_(LogSum a)
 #define LP(i) do { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define LP(i) do { } while (0)
-#endif
-#ifdef NMPC_LIDAR_X_NOLOG      // timing experiments (wrong results)
-#define LOGF(x) (x)
-#else
-#define LOGF(x) log(x)
-#endif
-#ifdef NMPC_LIDAR_X_NODIV
-#define DIVF(a, b) ((a) * (b))
-#else
-#define DIVF(a, b) ((a) / (b))
 #endif
 #define SV(off, k, c) wsb[(off) + (c) * NP1 + (k)]            // state-like arrays [3 + R][N + 1]
 #define RV(off, k, m) wsb[(off) + (m) * N + ((k) - 1)]        // per-ray arrays [R][N], stages 1..N
@@ -787,10 +779,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             double a_p = 1.0, a_d = 1.0, dphi = dphi_f, thh = 0.0;
             LogSum lgs_;
             auto slot = [&](double s_, double z_, double h_, double jd_) {
-                const double ds_ = jd_ + (h_ - s_), dz_ = DIVF(mu - s_ * z_ - z_ * ds_, s_);
-                if (ds_ < 0.0) a_p = fmin(a_p, DIVF(-tau * s_, ds_));
-                if (dz_ < 0.0) a_d = fmin(a_d, DIVF(-tau * z_, dz_));
-                dphi -= DIVF(mu * ds_, s_); lgs_.add(s_); thh += fabs(h_ - s_);
+                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
+                if (ds_ < 0.0) a_p = fmin(a_p, -tau * s_ / ds_);
+                if (dz_ < 0.0) a_d = fmin(a_d, -tau * z_ / dz_);
+                dphi -= mu * ds_ / s_; lgs_.add(s_); thh += fabs(h_ - s_);
             };
             {
                 auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double zl, double su, double zu) {
