@@ -50,14 +50,16 @@ def make(name, cfg, P):
 
 
 def lidar_cases():
-    """(name, LidarConfig, pose, goal) of tests/golden/slsqp_lidar.npz: three triples with aligned bounds and one with the bounds exactly as
+    """(name, LidarConfig, pose, goal) of tests/golden/slsqp_lidar.npz: four triples with aligned bounds and one with the bounds exactly as
     the script builds them (V4:161-176: misaligned with its own packing — from some stage on the POSE entries carry the distance
     bounds [0.15, 10])."""
     from oracle import lidar_ref as LR
     return [("a", LR.LidarConfig(N=10, Nc=5, R=3, aligned_bounds=True), np.array([0.0, 0.0, 0.1]), np.array([1.5, 0.8, 0.0])),
             ("b", LR.LidarConfig(N=10, Nc=5, R=3, aligned_bounds=True), np.array([0.3, -0.2, 1.0]), np.array([-1.0, 0.5, 0.5])),
             ("c", LR.LidarConfig(N=15, Nc=8, R=4, aligned_bounds=True), np.array([0.1, 0.0, 0.4]), np.array([1.8, 1.2, 0.3])),
-            ("d_script_bounds", LR.LidarConfig(N=12, Nc=6, R=4), np.array([0.2, 0.25, 0.3]), np.array([1.5, 1.0, 0.5]))]
+            ("d_script_bounds", LR.LidarConfig(N=12, Nc=6, R=4), np.array([0.2, 0.25, 0.3]), np.array([1.5, 1.0, 0.5])),
+            # R = 10 rays as in V3 / V4: the ray count the HIP kernel is specialised for (round 3)
+            ("e_ten_rays", LR.LidarConfig(N=8, Nc=4, R=10, aligned_bounds=True), np.array([0.1, 0.05, 0.5]), np.array([1.6, 1.1, 0.2]))]
 
 
 LIDAR_WORLD = [(1.2, 0.9, 0.25), (2.0, 2.2, 0.3)]      # the obstacle world of tests/test_oracle_lidar.py

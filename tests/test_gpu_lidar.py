@@ -220,8 +220,9 @@ def test_lidar_edge_cases(built):
 
 def test_hip_lidar_matches_slsqp_golden(built):
     """the HIP LIDAR solve DIRECTLY against tests/golden/slsqp_lidar.npz (scipy-SLSQP on the restated NLP — an independent solver, "not
-    CasADi/IPOPT"), tolerances of tests/test_oracle_lidar.py: objective 1e-6 relative, iterate 2e-4 (SLSQP's own accuracy); three triples with
-    aligned bounds and one with the bounds exactly as the script builds them (V4:161-176)."""
+    CasADi/IPOPT"), tolerances of tests/test_oracle_lidar.py: objective 1e-6 relative, iterate 2e-4 (SLSQP's own accuracy); four triples with
+    aligned bounds — one of them with R = 10 rays, the count the kernel is specialised for — and one with the bounds exactly as the script
+    builds them (V4:161-176)."""
     import torch
     import nmpc_amd
     from tests.test_oracle_lidar import _lidar_golden
@@ -237,7 +238,7 @@ def test_hip_lidar_matches_slsqp_golden(built):
         assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, (name, k)
         print(f"lidar golden {name}: |f - f_slsqp| = {abs(r['f'][0] - fs):.2e}, max|w - w_slsqp| = {np.abs(r['x'][0] - ws).max():.2e}, iters {r['iters'][0]}")
         n += 1
-    assert n == 4
+    assert n == 5
 
 
 def test_lidar_two_long_horizon_handles_and_reproducible_objective(built):

@@ -102,7 +102,7 @@ def _lidar_golden():
 
 
 def test_oracle_matches_slsqp_lidar_golden():
-    """the committed SLSQP triples of the LIDAR-state NLP, one of them with the bounds exactly as the script builds them."""
+    """the committed SLSQP triples of the LIDAR-state NLP (R = 3, 4 and 10 rays), one of them with the bounds exactly as the script builds them."""
     n = 0
     for name, cfg, p, w0, ws, fs in _lidar_golden():
         lbx, ubx, _, _ = LR.bounds(cfg)
@@ -111,7 +111,7 @@ def test_oracle_matches_slsqp_lidar_golden():
         assert abs(r["f"][0] - fs) <= 1e-6 * max(1.0, abs(fs)), (name, r["f"][0], fs)
         assert np.abs(r["x"][0] - ws).max() < 2e-4, (name, np.abs(r["x"][0] - ws).max())
         n += 1
-    assert n == 4
+    assert n == 5
 
 
 def test_oracles_are_clean_under_asan_and_ubsan():
