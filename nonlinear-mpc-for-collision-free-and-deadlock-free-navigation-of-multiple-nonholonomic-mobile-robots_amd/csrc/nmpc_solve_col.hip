@@ -36,7 +36,7 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #define NMPC_COL_GB ((M_ == 6) ? (NX + 2) / 2 : NX + 1)      // rows per batch of the G = P [B A] gathers.  Measured: six robots in two batches +2.7 % (batch of 3 -> 166 k, 5 -> 171 k, 10 -> 172 k, 13 -> 173 k, all 19 rows at once -> 165 k solves/s); two robots +-0, ten robots -2.5 %: one batch there
 #endif
 #ifndef NMPC_FW_PD
-#define NMPC_FW_PD 1         // stages the forward sweep requests its rows ahead (measured on the row-paired kernel: 1 -> 198.5 k, 2 -> 194 k, 3 -> 191 k, 4 -> 176 k solves/s; B=16384: 299 k vs 290 k — the rows come from L2, the ring costs registers)
+#define NMPC_FW_PD ((M_ <= 6) ? 2 : 1)         // stages the forward sweep requests its rows ahead.  The rows come from L2 and the ring costs registers: with the spills of the earlier builds 1 was best (1 -> 198.5 k, 2 -> 194 k, 3 -> 191 k, 4 -> 176 k solves/s); on the spill-free build (A/B, one session) 2: six robots +1.3..2.5 %, B=16384 +1 %, two robots +2 %, 3: -22 % (the ring is spilled); ten robots 2: -1.6 %, stays 1
 #endif
 #ifndef NMPC_FW_FAKE
 #define NMPC_FW_FAKE 0       // development: 1 = the forward sweep re-reads stage 0's rows (wrong results; separates compute from memory time)
