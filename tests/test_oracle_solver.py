@@ -146,6 +146,12 @@ def test_stall_case_and_composite_failures_are_rescued_by_the_cold_start_retry()
     z2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cold_retry_cases2.npz"))
     r2 = O.solve_batch(O.make_config(c, max_iter=2000), z2["p"], z2["w"])
     assert len(z2["p"]) == 5 and (r2["status"] == 0).all() and (r2["kkt"] <= 1e-8).all(), (r2["status"], r2["iters"])
+    # chaotic_composite_case.npz: the one solve of a 512 x 120 composite soak the HIP kernels of round 3's final build do not converge
+    # (tests/test_gpu_parity.py: same path as the oracle for 20 iterations, then rounding differences grow ~30x per six iterations); the
+    # oracle's own path converges in 134 iterations
+    zc = np.load(os.path.join(os.path.dirname(__file__), "golden", "chaotic_composite_case.npz"))
+    rc_ = O.solve_batch(O.make_config(c, max_iter=2000), zc["p"][None], zc["w"][None])
+    assert rc_["status"][0] == 0 and rc_["kkt"][0] <= 1e-8 and 100 <= rc_["iters"][0] <= 170, (rc_["status"], rc_["iters"])
     # without the retry the same inputs fail (what the fixture was captured for)
     import subprocess, sys
     code = ("import numpy as np, sys; sys.path.insert(0, %r); from oracle import nlp_ref as R, oracle_lib as O; "
