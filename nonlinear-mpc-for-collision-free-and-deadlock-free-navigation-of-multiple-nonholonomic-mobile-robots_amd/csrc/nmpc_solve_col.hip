@@ -110,6 +110,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     static_assert(TPBK == 64 || TPBK == 128 || TPBK == 256, "one, two or four wavefronts per instance");
     constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
     constexpr int NPd = NP > 0 ? NP : 1;   // divisor that stays legal for M_ == 1 (those loops have zero trips)
+    constexpr int MPN = M_ > 1 ? M_ - 1 : 1;   // partners of a robot in the pair rows
     static_assert(NZ <= 64, "one lane per column of the augmented matrix");
     constexpr int NR = (NZ + 15) / 16;     // rows of 16 lanes that hold columns
     // row-paired backward sweep (two to six robots): MP robots per half, NC control + NS state register slots, slot RR = right-hand side
@@ -216,9 +217,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     {
         double bad = 0.0;
         for (int q = tid; q < NPA; q += TPB) {
-            int i = 0, r = q;
-            while (r >= M_ - 1 - i) { r -= M_ - 1 - i; i++; }
-            int j = i + 1 + r;
+            int i, j;
+            pair_of<M_>(q, i, j);
             double dx = X[3 * i] - X[3 * j], dy = X[3 * i + 1] - X[3 * j + 1];
             if (h_pair(dx, dy, P.dmin2) < -NMPC_X0_TOL) bad = 1.0;
         }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     }
 
     // pair (i,j) of flat index q
-    auto pair_ij = [&](int q, int &i, int &j) { i = 0; while (q >= M_ - 1 - i) { q -= M_ - 1 - i; i++; } j = i + 1 + q; };
+    auto pair_ij = [&](int q, int &i, int &j) { pair_of<M_>(q, i, j); };      // loop-free (nmpc_solve_common.h): the while-loop form was a divergent loop, ~60 issue slots per call
 
     // ---- trig cache of the current iterate
     auto trig = [&]() {
@@ -439,12 +439,14 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             }
             if (kk <= N - 1) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
-#pragma unroll 1
-                for (int j = 0; j < (prs ? M_ : 0); j++) {
-                    if (j == i) continue;
-                    int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
-                    double z = ZPp[kk * NP + q];
-                    j0 += 2 * (xi - x[3 * j]) * z; j1 += 2 * (yi - x[3 * j + 1]) * z;
+                if (prs) {       // partners in ascending order (p-th partner: j = p, or p + 1 from the own index on); their duals requested first
+                    double zq[MPN];
+                    static_for<0, M_ - 1>([&](auto pc) { constexpr int p = decltype(pc)::value; zq[p] = ZPp[kk * NP + pidx_any<M_>(i, p + (p >= i ? 1 : 0))]; });
+                    static_for<0, M_ - 1>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        const int j = p + (p >= i ? 1 : 0);
+                        j0 += 2 * (xi - x[3 * j]) * zq[p]; j1 += 2 * (yi - x[3 * j + 1]) * zq[p];
+                    });
                 }
                 for (int o = 0; o < K; o++) {
                     double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), z = ZO[kk * MK + i * K + o];
@@ -527,15 +529,22 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 }
                 if (k <= N - 1) {
                     const double xi = x[3 * i], yi = x[3 * i + 1];
-#pragma unroll 1
-                    for (int j = 0; j < (prs ? M_ : 0); j++) {
-                        if (j == i) continue;
-                        int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
-                        double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
-                        double sv = SPp[k * NP + q], zv = ZPp[k * NP + q], sg = zv / sv;
-                        double v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv);
-                        g0 -= 2 * dx * v; g1 -= 2 * dy * v;
-                        h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
+                    if (prs) {
+                        double sq[MPN], zq[MPN];
+                        static_for<0, M_ - 1>([&](auto pc) {
+                            constexpr int p = decltype(pc)::value;
+                            const int q = pidx_any<M_>(i, p + (p >= i ? 1 : 0));
+                            sq[p] = SPp[k * NP + q]; zq[p] = ZPp[k * NP + q];
+                        });
+                        static_for<0, M_ - 1>([&](auto pc) {
+                            constexpr int p = decltype(pc)::value;
+                            const int j = p + (p >= i ? 1 : 0);
+                            double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
+                            double sv = sq[p], zv = zq[p], sg = zv / sv;
+                            double v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv);
+                            g0 -= 2 * dx * v; g1 -= 2 * dy * v;
+                            h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
+                        });
                     }
                     for (int o = 0; o < K; o++) {
                         double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = dx / rr, n1 = dy / rr;
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 double thr = 0.0;
                 static_for<0, NC>([&](auto ic) { constexpr int i = decltype(ic)::value; thr = (rh == rw && rn == i) ? m[i] : thr; });
                 thr = 1e-9 * fabs(thr);
-                auto pivot_inv = [&](double d) { return (d > thr && d > 0.0) ? rcp_nr(d) : -1.0; };
+                auto pivot_inv = [&](double d) { return (d > thr) ? rcp_nr(d) : -1.0; };      // thr >= 0 (or NaN, which rejects): d > thr already says d > 0
                 double inv_cur = lane_read(pivot_inv(m[rp_slot(0)]), 48 * rp_half(0) + rp_slot(0));
                 double rhsv = 0.0;
                 bool okk = true;
@@ -1166,17 +1175,24 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             }
             if (k < N) {
                 const double xi = x[3 * i], yi = x[3 * i + 1];
-#pragma unroll 1
-                for (int j = 0; j < (prs ? M_ : 0); j++) {
-                    if (j == i) continue;
-                    int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
-                    double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
-                    double ddx = dx[3 * i] - dx[3 * j], ddy = dx[3 * i + 1] - dx[3 * j + 1];
-                    double sv = SPp[k * NP + q], zv = ZPp[k * NP + q];
-                    double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv);
-                    double znew = zv + dz_of(mu, sv, zv, ds);
-                    l0 += 2 * ex * znew + 2 * zv * ddx;      // Jx^T (z+dz)  -  (-2 z (ddx))  [exact-Hessian term of the pair row]
-                    l1 += 2 * ey * znew + 2 * zv * ddy;
+                if (prs) {
+                    double sq[MPN], zq[MPN];
+                    static_for<0, M_ - 1>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        const int q = pidx_any<M_>(i, p + (p >= i ? 1 : 0));
+                        sq[p] = SPp[k * NP + q]; zq[p] = ZPp[k * NP + q];
+                    });
+                    static_for<0, M_ - 1>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        const int j = p + (p >= i ? 1 : 0);
+                        double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
+                        double ddx = dx[3 * i] - dx[3 * j], ddy = dx[3 * i + 1] - dx[3 * j + 1];
+                        double sv = sq[p], zv = zq[p];
+                        double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv);
+                        double znew = zv + dz_of(mu, sv, zv, ds);
+                        l0 += 2 * ex * znew + 2 * zv * ddx;      // Jx^T (z+dz)  -  (-2 z (ddx))  [exact-Hessian term of the pair row]
+                        l1 += 2 * ey * znew + 2 * zv * ddy;
+                    });
                 }
                 for (int o = 0; o < K; o++) {
                     double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = ex / rr, n1 = ey / rr;

@@ -102,6 +102,38 @@ __device__ __forceinline__ double rcp_nr(double d)
 
 template <int M_> __device__ __forceinline__ int pidx(int a, int b) { return a * (2 * M_ - a - 1) / 2 + (b - a - 1); }
 
+// flat index of the unordered pair {a, b}, a != b
+template <int M_> __device__ __forceinline__ int pidx_any(int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return pidx<M_>(lo, hi); }
+
+// Inverse of pidx: pair (i < j) of flat index q (lexicographic order 12, 13, .., 1m, 23, .. of C6:288-306), without a loop.  The obvious
+// `while (q >= M-1-i) { q -= M-1-i; i++; }` compiles to a DIVERGENT loop (11 instructions per trip, every lane waits for the lane with the
+// largest i): ~60 issue slots per call, 25 calls per interior-point iteration of six robots.  Up to six robots (<= 15 pairs) i and j are
+// 4-bit fields of two 64-bit literals; beyond, i counts the row starts c_r = r (2M-1-r)/2 that q has passed.
+template <int M_> struct PairTab {
+    static constexpr int NP = M_ * (M_ - 1) / 2;
+    static constexpr unsigned long long tab(bool want_j)
+    {
+        unsigned long long t = 0;
+        int q = 0;
+        for (int i = 0; i < M_ && q < 16; i++)
+            for (int j = i + 1; j < M_ && q < 16; j++, q++) t |= (unsigned long long)(want_j ? j : i) << (4 * q);
+        return t;
+    }
+};
+template <int M_> __device__ __forceinline__ void pair_of(int q, int &i, int &j)
+{
+    if constexpr (M_ * (M_ - 1) / 2 <= 16) {
+        constexpr unsigned long long TI = PairTab<M_>::tab(false), TJ = PairTab<M_>::tab(true);
+        const int sh = 4 * q;
+        i = (int)((TI >> sh) & 15ull); j = (int)((TJ >> sh) & 15ull);
+    } else {
+        int r = 0;
+#pragma unroll
+        for (int s = 1; s < M_ - 1; s++) r += (q >= s * (2 * M_ - 1 - s) / 2) ? 1 : 0;
+        i = r; j = q - r * (2 * M_ - 1 - r) / 2 + r + 1;
+    }
+}
+
 // A value every lane of the wave holds identically (a finished reduction, an LDS word read at a wave-uniform address),
 // moved through v_readfirstlane: the compiler then KNOWS it is wave-uniform, so the branches that depend on it (line-search
 // acceptance, convergence, pivot failure, barrier update) become scalar branches instead of exec-masked divergent regions.
