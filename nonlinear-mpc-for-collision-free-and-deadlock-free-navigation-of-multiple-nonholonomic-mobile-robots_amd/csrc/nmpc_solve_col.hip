@@ -50,6 +50,9 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #ifndef NMPC_COL_WAVES_MID
 #define NMPC_COL_WAVES_MID 1        // occupancy the compiler is ASKED for, four to six robots (see col_min_waves)
 #endif
+#ifndef NMPC_COL_DUMMY_ST
+#define NMPC_COL_DUMMY_ST (NU - 1)
+#endif
 #ifndef NMPC_COL_RP
 #define NMPC_COL_RP 1        // row-paired backward sweep for two to six robots (see the sweep); 0 keeps one row per register (A/B)
 #endif
@@ -670,6 +673,13 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 #pragma unroll
             for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
             double pend_row = 0.0, pend_rhs = 0.0;
+#if NMPC_COL_DUMMY_ST
+            // vmcnt counts loads and stores in issue order.  The wait for a stage's pack (requested at the top of the previous stage) may leave
+            // the NU - 1 pivot-row stores issued after that request in flight — but the compiler merges the counter state of the loop's two
+            // entries, and on the path from here nothing follows the first request, so it waited for vmcnt(3..0): every stage began with the
+            // acknowledgement latency of the previous stage's last stores.  As many (padding-slot) stores here make the two paths alike.
+            static_for<0, NMPC_COL_DUMMY_ST>([&](auto jc) { gkt[(size_t)(N - 1) * G::KTS + decltype(jc)::value * G::LDC + NZ + 1] = 0.0; });
+#endif
             for (int k = N - 1; k >= 0; k--) {
                 lds_sync<TPB>();
 #pragma unroll
