@@ -151,8 +151,10 @@ def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id, wname="s
     flops_launch = float(sum_iters) * fl_iter
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
     # the kernel nmpc_solve_batch picked for this team size and batch, as the library reports it (nmpc_query):
-    # 3 column-per-lane (throughput batches), 2 element-per-lane (latency shapes), 1 HBM-resident fallback
-    kname = {3: "nmpc::solve_col_kernel<%d,...>", 2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % ocfg.m
+    # 3 column-per-lane, throughput shape (one wavefront per instance); 4 the same kernel's latency shape (two wavefronts per instance, four
+    # where the library's rule says so: the composite); 2 element-per-lane; 1 HBM-resident fallback
+    kname = {3: "nmpc::solve_col_kernel<%d,...,64>", 4: "nmpc::solve_col_kernel<%d,...,128|256> (latency shape)", 5: "nmpc::solve_col_kernel<%d,...,256>",
+             2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % ocfg.m
     rl = {"bound": "fp64-valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
           "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,

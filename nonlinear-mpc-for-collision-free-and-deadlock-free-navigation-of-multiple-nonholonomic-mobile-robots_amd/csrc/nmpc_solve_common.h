@@ -120,7 +120,7 @@ template <int M_> struct PairTab {
         return t;
     }
 };
-template <int M_> __device__ __forceinline__ void pair_of(int q, int &i, int &j)
+template <int M_> __host__ __device__ __forceinline__ constexpr void pair_of(int q, int &i, int &j)
 {
     if constexpr (M_ * (M_ - 1) / 2 <= 16) {
         constexpr unsigned long long TI = PairTab<M_>::tab(false), TJ = PairTab<M_>::tab(true);
@@ -133,6 +133,20 @@ template <int M_> __device__ __forceinline__ void pair_of(int q, int &i, int &j)
         i = r; j = q - r * (2 * M_ - 1 - r) / 2 + r + 1;
     }
 }
+// compile-time check of pair_of against the definition (the lexicographic enumeration) for every team size the kernels are instantiated for
+template <int M_> constexpr bool pair_of_ok()
+{
+    int q = 0;
+    for (int i = 0; i < M_; i++)
+        for (int j = i + 1; j < M_; j++, q++) {
+            int a = -1, b = -1;
+            pair_of<M_>(q, a, b);
+            if (a != i || b != j || a * (2 * M_ - a - 1) / 2 + (b - a - 1) != q) return false;
+        }
+    return q == M_ * (M_ - 1) / 2;
+}
+static_assert(pair_of_ok<1>() && pair_of_ok<2>() && pair_of_ok<3>() && pair_of_ok<4>() && pair_of_ok<5>() && pair_of_ok<6>() && pair_of_ok<7>() &&
+              pair_of_ok<8>() && pair_of_ok<9>() && pair_of_ok<10>(), "pair_of is the inverse of pidx");
 
 // A value every lane of the wave holds identically (a finished reduction, an LDS word read at a wave-uniform address),
 // moved through v_readfirstlane: the compiler then KNOWS it is wave-uniform, so the branches that depend on it (line-search
