@@ -843,6 +843,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             // stage's pack: vmcnt counts loads and stores in order, so a store issued just before the wait adds its whole
             // acknowledgement latency to it
             double pend_row = 0.0, pend_rhs = 0.0;
+#if NMPC_COL_DUMMY_ST
+            static_for<0, NMPC_COL_DUMMY_ST>([&](auto jc) { gkt[(size_t)(N - 1) * G::KTS + decltype(jc)::value * G::LDC + NZ + 1] = 0.0; });      // (see the row-paired sweep)
+#endif
             for (int k = N - 1; k >= 0; k--) {
                 // ---- stage pack -> LDS (the inertia shift delta joins the control diagonal here); prefetch the next one
                 lds_sync<TPB>();         // every read of the previous stage's pack is done
@@ -900,15 +903,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 //      broadcast inside the multiply-add (row_newbcast DPP operand), one DP instruction per remaining row
                 double d0s[NU];                          // the control diagonals as assembled (pivot test reference), wave-uniform
                 static_for<0, NU>([&](auto jc) { constexpr int j = decltype(jc)::value; d0s[j] = lane_read(m[j], LC(j)); });
-                auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0) && d > 0.0) ? rcp_nr(d) : -1.0; };
+                auto pivot_inv = [&](double d, double d0) { return (d > 1e-9 * fabs(d0)) ? rcp_nr(d) : -1.0; };      // the bound is >= 0 (or NaN, which rejects): no separate d > 0
                 double inv_cur = pivot_inv(d0s[0], d0s[0]);
                 double rhsv = 0.0;                       // lane j <- right-hand side of pivot row j, times -1/pivot
+                bool okk = true;                         // a rejected pivot does not leave the stage early (as in the row-paired sweep): no branch per pivot
                 static_for<0, NU>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    if (ok) {
+                    {
                         const double inv = inv_cur;
-                        if (!(inv > 0.0)) ok = false;
-                        else {
+                        okk = okk && (inv > 0.0);
+                        {
                             const double rhs_j = lane_read(m[NZ], LC(j));
                             rhsv = (tid == j) ? -rhs_j * inv : rhsv;
                             const double rjv = m[j] * inv;
@@ -955,6 +959,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                         }
                     }
                 });
+                ok = okk;
                 PROF_T(11);
                 if (!ok) break;
                 // the right-hand sides of the pivot rows (lanes 0..NU-1 hold them)
