@@ -938,8 +938,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                                 ur[3] = ur[1]; swap32(ur[1], ur[3]);
                             }
                             // VALU write -> DPP read of the same VGPR needs 2 wait states (no VALU writes EXEC here); hipcc does not look into asm
-                            if constexpr (NR >= 2) { asm("s_nop 1" : "+v"(ur[0])); asm("s_nop 0" : "+v"(ur[1])); }
-                            if constexpr (NR >= 3) { asm("s_nop 0" : "+v"(ur[2])); asm("s_nop 0" : "+v"(ur[3])); }
+                            // ONE s_nop behind the last of the writes covers all the replicas (it was one per register: four issue slots per pivot)
+                            if constexpr (NR == 2) asm("s_nop 1" : "+v"(ur[0]), "+v"(ur[1]));
+                            if constexpr (NR >= 3) asm("s_nop 1" : "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]));
                             auto elim = [&](auto ac) {
                                 constexpr int a = decltype(ac)::value;
                                 fmac_rowb<(LC(a) & 15)>(m[a], ur[LC(a) >> 4], nrjv);
