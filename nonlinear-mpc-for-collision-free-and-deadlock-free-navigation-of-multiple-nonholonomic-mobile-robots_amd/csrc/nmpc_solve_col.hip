@@ -326,6 +326,20 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
         ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
     };
 
+    // ---- constant entries of the stage packs (coefficients of [B A] that do not depend on the iterate, the zero slot): once per solve
+    for (int it = tid; it < N * M_; it += TPB) {
+        int k = it / M_, i = it - k * M_;
+        double *cf = gpack + (size_t)k * G::PACK + G::PK_CF;
+        cf[3 * (2 * i) + 2] = 0.0;
+        cf[3 * (2 * i + 1)] = T; cf[3 * (2 * i + 1) + 1] = 0.0; cf[3 * (2 * i + 1) + 2] = 0.0;
+        cf[3 * (NU + 3 * i)] = 1.0; cf[3 * (NU + 3 * i) + 1] = 0.0; cf[3 * (NU + 3 * i) + 2] = 0.0;
+        cf[3 * (NU + 3 * i + 1)] = 1.0; cf[3 * (NU + 3 * i + 1) + 1] = 0.0; cf[3 * (NU + 3 * i + 1) + 2] = 0.0;
+        cf[3 * (NU + 3 * i + 2)] = 1.0;
+        if (i == 0) gpack[(size_t)k * G::PACK + G::PK_ZERO] = 0.0;
+    }
+    for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
+    if (!prs)                                                              // no pair rows at all: the E slots of every stage are zero
+        for (int e = tid; e < (N - 1) * 3 * NP; e += TPB) gpack[(size_t)(1 + e / (3 * NPd)) * G::PACK + G::PK_E + e % (3 * NPd)] = 0.0;
     double mu = P.mu_init;
     // ---- slacks and duals from the current primal point (also the barrier restart after a stall)
     auto init_barrier = [&]() {
@@ -573,14 +587,11 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                     pk[G::PK_G + 2 * i + d] = 2 * P.r[d] * u[d] - (vl - vu);
                     pk[G::PK_HD + 2 * i + d] = 2 * P.r[d] + zl / sl + zu / su;
                 }
-                {   // rows/columns of [B A] belonging to robot i: v_i, omega_i, x_i, y_i, theta_i
+                {   // rows/columns of [B A] belonging to robot i: v_i, omega_i, x_i, y_i, theta_i — the entries that depend on the iterate
+                    // (the constant ones are written once per solve, below the start of the kernel)
                     double *cf = pk + G::PK_CF;
-                    cf[3 * (2 * i)] = T * c; cf[3 * (2 * i) + 1] = T * s; cf[3 * (2 * i) + 2] = 0.0;
-                    cf[3 * (2 * i + 1)] = T; cf[3 * (2 * i + 1) + 1] = 0.0; cf[3 * (2 * i + 1) + 2] = 0.0;
-                    cf[3 * (NU + 3 * i)] = 1.0; cf[3 * (NU + 3 * i) + 1] = 0.0; cf[3 * (NU + 3 * i) + 2] = 0.0;
-                    cf[3 * (NU + 3 * i + 1)] = 1.0; cf[3 * (NU + 3 * i + 1) + 1] = 0.0; cf[3 * (NU + 3 * i + 1) + 2] = 0.0;
-                    cf[3 * (NU + 3 * i + 2)] = 1.0; cf[3 * (NU + 3 * i + 2) + 1] = -T * u[0] * s; cf[3 * (NU + 3 * i + 2) + 2] = T * u[0] * c;
-                    if (i == 0) pk[G::PK_ZERO] = 0.0;
+                    cf[3 * (2 * i)] = T * c; cf[3 * (2 * i) + 1] = T * s;
+                    cf[3 * (NU + 3 * i + 2) + 1] = -T * u[0] * s; cf[3 * (NU + 3 * i + 2) + 2] = T * u[0] * c;
                 }
                 const double *xn = x + NX;
                 pk[G::PK_C + 3 * i] = defect_xy(xn[3 * i], x[3 * i], T * u[0], c);
@@ -601,9 +612,6 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double *pk = gpack + (size_t)k * G::PACK + G::PK_E + 3 * q;
             pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
         }
-        for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
-        if (!prs)                                                              // no pair rows at all: the E slots of every stage are zero
-            for (int e = tid; e < (N - 1) * 3 * NP; e += TPB) gpack[(size_t)(1 + e / (3 * NPd)) * G::PACK + G::PK_E + e % (3 * NPd)] = 0.0;
         __syncthreads();
         PROF_T(2);
 
