@@ -98,6 +98,20 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
 }
 
+// Stage pack of this kernel: G2's layout with a COMPACT coefficient table.  G2 keeps three coefficients for each of the NZ columns of [B A]
+// (3 NZ doubles, most of them 0, 1 or T); here PK_CF holds the four entries per robot that depend on the iterate — T cos, T sin, -T v sin,
+// T v cos — followed by one slot with T and the zero slot: 168 instead of 232 doubles for six robots, i.e. three 64-lane slices to stage per
+// stage instead of four and 26 KB less traffic per iteration.  (The workspace is sized for G2's pack; the element-per-lane kernel keeps G2.)
+template <int M_, int THB> struct GC : G2<M_, THB> {
+    using B = G2<M_, THB>;
+    static constexpr int PK_CF = B::PK_CF;           // [4 M]
+    static constexpr int PK_T = PK_CF + 4 * M_;      // T
+    static constexpr int PK_ZERO = PK_T + 1;         // one zero entry (target of "no Hessian addition" / "no coefficient")
+    static constexpr int PACKC = ((PK_ZERO + 1 + 7) / 8) * 8;
+    static constexpr int PACK = (PACKC < 64 && B::PACK >= 64) ? 64 : PACKC;      // two robots: one whole 64-lane slice, as before (no exec-masked staging)
+    static_assert(PACK <= B::PACK, "the workspace is sized for G2's pack");
+};
+
 // TPBK: threads per instance.  64 = the throughput shape (one wavefront per instance).  128 (256) = the LATENCY shape: a second wavefront (three more) shares
 // the stage-parallel phases (evaluation, optimality error, stage packs, step lengths, multipliers, merit function, update — 41 % of a lone
 // wave's iteration for six robots) and waits at a barrier while wave 0 runs the two sweeps; for batches whose launch is as long as their
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                                                         int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out,
                                                         double *__restrict__ kkt_out, double *__restrict__ ws, long long *__restrict__ prof_out)
 {
-    using G = G2<M_, THB>;
+    using G = GC<M_, THB>;
     constexpr int TPB = TPBK;
     static_assert(TPBK == 64 || TPBK == 128 || TPBK == 256, "one, two or four wavefronts per instance");
     constexpr int NX = G::NX, NU = G::NU, NP = G::NP, NZ = G::NZ, LD = G::LD, NXB = G::NXB;
@@ -326,16 +340,10 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
         ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
     };
 
-    // ---- constant entries of the stage packs (coefficients of [B A] that do not depend on the iterate, the zero slot): once per solve
+    // ---- constant entries of the stage packs (the T and zero slots, stage 0's pair blocks): once per solve
     for (int it = tid; it < N * M_; it += TPB) {
         int k = it / M_, i = it - k * M_;
-        double *cf = gpack + (size_t)k * G::PACK + G::PK_CF;
-        cf[3 * (2 * i) + 2] = 0.0;
-        cf[3 * (2 * i + 1)] = T; cf[3 * (2 * i + 1) + 1] = 0.0; cf[3 * (2 * i + 1) + 2] = 0.0;
-        cf[3 * (NU + 3 * i)] = 1.0; cf[3 * (NU + 3 * i) + 1] = 0.0; cf[3 * (NU + 3 * i) + 2] = 0.0;
-        cf[3 * (NU + 3 * i + 1)] = 1.0; cf[3 * (NU + 3 * i + 1) + 1] = 0.0; cf[3 * (NU + 3 * i + 1) + 2] = 0.0;
-        cf[3 * (NU + 3 * i + 2)] = 1.0;
-        if (i == 0) gpack[(size_t)k * G::PACK + G::PK_ZERO] = 0.0;
+        if (i == 0) { gpack[(size_t)k * G::PACK + G::PK_T] = T; gpack[(size_t)k * G::PACK + G::PK_ZERO] = 0.0; }
     }
     for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
     if (!prs)                                                              // no pair rows at all: the E slots of every stage are zero
@@ -587,11 +595,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                     pk[G::PK_G + 2 * i + d] = 2 * P.r[d] * u[d] - (vl - vu);
                     pk[G::PK_HD + 2 * i + d] = 2 * P.r[d] + zl / sl + zu / su;
                 }
-                {   // rows/columns of [B A] belonging to robot i: v_i, omega_i, x_i, y_i, theta_i — the entries that depend on the iterate
-                    // (the constant ones are written once per solve, below the start of the kernel)
-                    double *cf = pk + G::PK_CF;
-                    cf[3 * (2 * i)] = T * c; cf[3 * (2 * i) + 1] = T * s;
-                    cf[3 * (NU + 3 * i + 2) + 1] = -T * u[0] * s; cf[3 * (NU + 3 * i + 2) + 2] = T * u[0] * c;
+                {   // coefficients of [B A] belonging to robot i that depend on the iterate: (v_i: x, y) = T cos, T sin; (theta_i: x, y) = -T v sin, T v cos
+                    double *cf = pk + G::PK_CF + 4 * i;
+                    cf[0] = T * c; cf[1] = T * s; cf[2] = -T * u[0] * s; cf[3] = T * u[0] * c;
                 }
                 const double *xn = x + NX;
                 pk[G::PK_C + 3 * i] = defect_xy(xn[3 * i], x[3 * i], T * u[0], c);
@@ -659,8 +665,11 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 h = (rcol == a) ? G::PK_HD + a : h;
                 hoff[i] = 8 * ((cvalid && rob < M_) ? h : G::PK_ZERO);
             });
-            const int goff = 8 * (cvalid ? G::PK_G + rcol : G::PK_ZERO), cfo = 8 * (G::PK_CF + 3 * rcol);
-            const int cbo = 8 * (G::PK_C + 3 * rh), cf1 = 8 * (G::PK_CF + 6 * rh), cf2 = 8 * (G::PK_CF + 3 * NU + 9 * rh);
+            const int goff = 8 * (cvalid ? G::PK_G + rcol : G::PK_ZERO);
+            // coefficients of the two gathered terms of my column of [B A]: theta_i <- (-T v sin, T v cos), v_i <- (T cos, T sin), omega_i <- (T, 0), else none
+            const int cfA = 8 * ((c_state && cd == 2) ? G::PK_CF + 4 * crob + 2 : ((c_ctrl && cd == 0) ? G::PK_CF + 4 * crob : ((c_ctrl && cd == 1) ? G::PK_T : G::PK_ZERO)));
+            const int cfB = 8 * ((c_state && cd == 2) ? G::PK_CF + 4 * crob + 3 : ((c_ctrl && cd == 0) ? G::PK_CF + 4 * crob + 1 : G::PK_ZERO));
+            const int cbo = 8 * (G::PK_C + 3 * rh), cf1 = 8 * (G::PK_CF + 4 * rh);
             // gather sources of G = P [B A] inside my wave-row:  theta_i, v_i <- x_i, y_i;  omega_i <- theta_i
             const int lb = tid & ~15;
             const bool needxy = (c_state && cd == 2) || (c_ctrl && cd == 0), needth = c_ctrl && cd == 1;
@@ -708,8 +717,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 }
                 double kO, kA, kB;
                 {
-                    const double c0 = lds_ld(PK, cfo, 0), c1 = lds_ld(PK, cfo, 8), c2 = lds_ld(PK, cfo, 16);
-                    kO = c_state ? c0 : 0.0; kA = c_state ? c1 : (c_ctrl ? c0 : 0.0); kB = c_state ? c2 : (c_ctrl ? c1 : 0.0);
+                    kO = c_state ? 1.0 : 0.0; kA = lds_ld(PK, cfA, 0); kB = lds_ld(PK, cfB, 0);
                 }
                 // ---- 1. right-hand side p + P b, b = -c_k: each half sums over its own state rows, the halves are then added
                 {
@@ -741,8 +749,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 // ---- 3. [B A]^T G: row operations inside each half (a robot's rows live in one half), coefficients per half
                 static_for<0, MP>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
-                    double Tc = lds_ld(PK, cf1, 8 * (12 * p)), Ts = lds_ld(PK, cf1, 8 * (12 * p + 1)), Tt = lds_ld(PK, cf1, 8 * (12 * p + 3));
-                    double ai = lds_ld(PK, cf2, 8 * (18 * p + 7)), bi = lds_ld(PK, cf2, 8 * (18 * p + 8));
+                    double Tc = lds_ld(PK, cf1, 8 * (8 * p)), Ts = lds_ld(PK, cf1, 8 * (8 * p + 1)), Tt = T;
+                    double ai = lds_ld(PK, cf1, 8 * (8 * p + 2)), bi = lds_ld(PK, cf1, 8 * (8 * p + 3));
                     if constexpr ((M_ & 1) && p == MP - 1) { Tc = rh ? 0.0 : Tc; Ts = rh ? 0.0 : Ts; Tt = rh ? 0.0 : Tt; ai = rh ? 0.0 : ai; bi = rh ? 0.0 : bi; }
                     const double gx = m[NC + 3 * p], gy = m[NC + 3 * p + 1], gt = m[NC + 3 * p + 2];
                     m[2 * p] = fma(Ts, gy, Tc * gx);
@@ -829,7 +837,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 h = (lvalid && mycol == a) ? G::PK_HD + a : h;
                 hoff[a] = 8 * (lvalid ? h : G::PK_ZERO);
             });
-            const int goff = 8 * (lvalid ? G::PK_G + mycol : G::PK_ZERO), cfo = 8 * (G::PK_CF + 3 * mycol);
+            const int goff = 8 * (lvalid ? G::PK_G + mycol : G::PK_ZERO);
+            const int cfA = 8 * (th_lane ? G::PK_CF + 4 * mrob + 2 : ((is_ctrl && !(ma & 1)) ? G::PK_CF + 4 * mrob : ((is_ctrl && (ma & 1)) ? G::PK_T : G::PK_ZERO)));
+            const int cfB = 8 * (th_lane ? G::PK_CF + 4 * mrob + 3 : ((is_ctrl && !(ma & 1)) ? G::PK_CF + 4 * mrob + 1 : G::PK_ZERO));
             // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N: rows NU.. of the state lanes
             double m[NZ + 1];
             {
@@ -875,8 +885,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 // coefficients of the <= 3 terms of my column of [B A]: own, gathered A, gathered B
                 double kO, kA, kB;
                 {
-                    const double c0 = lds_ld(PK, cfo, 0), c1 = lds_ld(PK, cfo, 8), c2 = lds_ld(PK, cfo, 16);
-                    kO = is_state ? c0 : 0.0; kA = is_state ? c1 : (is_ctrl ? c0 : 0.0); kB = is_state ? c2 : (is_ctrl ? c1 : 0.0);
+                    kO = is_state ? 1.0 : 0.0; kA = lds_ld(PK, cfA, 0); kB = lds_ld(PK, cfB, 0);
                 }
                 // ---- 1. right-hand side p + P b, b = -c_k (defects broadcast from the pack)
                 static_for<0, NX>([&](auto sc) { constexpr int s = decltype(sc)::value; m[NZ] = fma(-m[NU + s], PK[G::PK_C + s], m[NZ]); });
@@ -896,8 +905,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 // ---- 3. [B A]^T G: a row operation, i.e. in-lane, with the wave-uniform coefficients of each robot
                 static_for<0, M_>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    const double Tc = PK[G::PK_CF + 3 * (2 * i)], Ts = PK[G::PK_CF + 3 * (2 * i) + 1], Tt = PK[G::PK_CF + 3 * (2 * i + 1)];
-                    const double ai = PK[G::PK_CF + 3 * (NU + 3 * i + 2) + 1], bi = PK[G::PK_CF + 3 * (NU + 3 * i + 2) + 2];
+                    const double Tc = PK[G::PK_CF + 4 * i], Ts = PK[G::PK_CF + 4 * i + 1], Tt = T;
+                    const double ai = PK[G::PK_CF + 4 * i + 2], bi = PK[G::PK_CF + 4 * i + 3];
                     const double gx = m[NU + 3 * i], gy = m[NU + 3 * i + 1], gt = m[NU + 3 * i + 2];
                     m[2 * i] = fma(Ts, gy, Tc * gx);
                     m[2 * i + 1] = Tt * gt;
