@@ -14,6 +14,16 @@
 #define NMPC_SHIFT_ESCALATION 8.0
 #endif
 
+/* Inertia correction, partial re-factorisation (round 4).  The backward sweep saves the cost-to-go entering every NMPC_CKPT_EVERY-th
+   stage (the stages k with (N-1-k) % NMPC_CKPT_EVERY == 0).  A rejected pivot at stage k escalates the shift and resumes the sweep at
+   NMPC_RESUME_STAGE(k, N): the nearest saved stage at or above min(k + NMPC_REFACTOR_BACK, N-1) — the stages above keep their
+   factorisation (and the smaller shift it was made with).  Measured on the oracle (tools/sreg_experiment.py): resuming AT
+   the failing stage (BACK = 0) costs 40 % more iterations, BACK >= 1 with EVERY >= 3 or BACK >= 2 none (4 % fewer than the whole-sweep retry). */
+#define NMPC_CKPT_EVERY 5
+#define NMPC_REFACTOR_BACK 2
+#define NMPC_RESUME_STAGE(k, N) ((((k) + NMPC_REFACTOR_BACK < (N) - 1) ? (k) + NMPC_REFACTOR_BACK : (N) - 1) + \
+                                 ((N) - 1 - (((k) + NMPC_REFACTOR_BACK < (N) - 1) ? (k) + NMPC_REFACTOR_BACK : (N) - 1)) % NMPC_CKPT_EVERY)
+
 /* Cold-start retry (restoration of last resort): a solve that stalls after its barrier restarts, fails numerically or is
    still iterating NMPC_COLD_RETRY_ITERS iterations into an attempt is restarted from the reference's cold start X_k = x0, U = 0
    (C6:398-400; LIDAR: V4:184-196), at most NMPC_COLD_RETRIES times, the second time with a ten times larger initial barrier parameter. */

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(ROOT, "lib")                # short in-tree path (see _lib.SO_PATH)
+LIBDIR = os.environ.get("NMPC_LIBDIR") or os.path.join(ROOT, "lib")      # short in-tree path (see _lib.SO_PATH); NMPC_LIBDIR: build somewhere else (the forced-build test: the shared in-tree artefact is not replaced under running processes)
 SO = os.path.join(LIBDIR, "libnmpc_hip.so")
 INFO = os.path.join(LIBDIR, "build_info.json")    # what the last build() call did: compiled or reused, and the source hash
 SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc_lidar.hip", "nmpc_api.cpp"]
@@ -103,7 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         flags.append("-DNMPC_COL_ONLY_M=" + only)
     # one hipcc -c per source, in parallel (the solve kernels dominate the build time), then link
     from concurrent.futures import ThreadPoolExecutor
-    objdir = os.path.join(HERE, "build")
+    objdir = os.environ.get("NMPC_OBJDIR") or os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     skip = set(filter(None, os.environ.get("NMPC_REUSE_OBJ", "").split(",")))   # development: keep the objects of unchanged sources
 

@@ -92,6 +92,7 @@ static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
     P->oSN = take((int64_t)N * m); P->oCS = take((int64_t)N * m); P->oC = take(nX); P->oH = take(nH); P->oGX = take(nX);
     P->oHUU = take(nU); P->oGU = take(nU); P->oHVT = take((int64_t)N * m); P->oHTT = take((int64_t)N * m);
     P->oKG = take((int64_t)N * nu * nx); P->oKFF = take(nU);
+    P->oCKP = take((int64_t)((N - 1) / NMPC_CKPT_EVERY + 1) * (nx * nx + nx));      // saved cost-to-go of the backward sweep (partial re-factorisation)
     P->stride = o;
     return 0;
 }
@@ -144,6 +145,12 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
         const int64_t dual = 2 * N1 * NPd + 2 * N1 * MK + 4 * N * NU + 2 * N1 * NXB;
         h->P.oDUAL = h->P.stride2;
         h->P.stride2 += (dual + 15) / 16 * 16;
+    }
+    {   // cost-to-go saved every NMPC_CKPT_EVERY stages of the backward sweep (partial re-factorisation after a rejected pivot): the column
+        // kernel stores its registers lane by lane, (3m + 1) x 64 doubles per slot; the element-per-lane kernel its [P | p] (smaller)
+        const int64_t slots = (cfg->N - 1) / NMPC_CKPT_EVERY + 1;
+        h->P.oCKPT = h->P.stride2;
+        h->P.stride2 += slots * (3 * cfg->m + 1) * 64;
     }
     int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
     h->ws_bytes = (int64_t)sizeof(double) * per * max_batch;

@@ -25,8 +25,9 @@ struct KParams {
     const int32_t *order_bad;   // device flag written by the permutation check of that order: non-zero -> the hint is ignored
     int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
     int64_t oPACK, oKT;
+    int64_t oCKPT;        // LDS-resident kernels: cost-to-go saved every NMPC_CKPT_EVERY stages of the backward sweep, [(N-1)/NMPC_CKPT_EVERY + 1] slots of (3m + 1) * 64 doubles
     int64_t oDUAL;        // column kernel: slacks and duals of the inequality rows (touched by the stage-parallel phases only) live here, not in LDS
-    int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF;
+    int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF, oCKP;      // oCKP: the HBM-resident kernel's saved cost-to-go, [(N-1)/NMPC_CKPT_EVERY + 1][nx * nx + nx]
 };
 
 hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     double *SN = base + P.oSN, *CS = base + P.oCS, *Cd = base + P.oC, *H = base + P.oH, *GX = base + P.oGX;
     double *HUU = base + P.oHUU, *GU = base + P.oGU, *HVT = base + P.oHVT, *HTT = base + P.oHTT;
     double *KG = base + P.oKG, *KFF = base + P.oKFF;
+    double *CKP = base + P.oCKP;      // saved cost-to-go [P | p] of the backward sweep, one slot of NX * NX + NX doubles per NMPC_CKPT_EVERY stages
 
     const double *pp = p_in + inst * (2 * NX);
     const double *wi = w0 + inst * (size_t)P.nvar;
@@ -449,21 +450,36 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         // ================= Riccati sweep with inertia correction (IPOPT alg. IC)
         // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
         double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
+        // Partial re-factorisation (include/nmpc_constants.h): [P | p] entering every NMPC_CKPT_EVERY-th stage is saved; a rejected pivot at
+        // stage kf escalates the shift and resumes at the saved stage NMPC_RESUME_STAGE(kf, N), the stages above keep their gains.
         int ntry = 0;
         bool ok;
+        int kst = N - 1;
         for (;;) {
             ok = true;
-            // terminal: P_N = Hxx_N + delta I (bound barrier terms only), p_N = gx_N
-            for (int e = tid; e < NX * NX; e += TPB) sP[e] = 0.0;
-            __syncthreads();
-            for (int c = tid; c < NX; c += TPB) sPv[c] = GX[N * NX + c];   // the inertia shift acts on the controls only
-            __syncthreads();
-            for (int s = tid; s < P.nxb; s += TPB) {
-                int c = bnd_state(P, s);
-                sP[c * NX + c] += Z[N * NH + P.o_xl + s] / S[N * NH + P.o_xl + s] + Z[N * NH + P.o_xu + s] / S[N * NH + P.o_xu + s];
+            int kf = 0;
+            if (kst == N - 1) {
+                // terminal: P_N = Hxx_N (bound barrier terms only), p_N = gx_N; the inertia shift acts on the controls only
+                for (int e = tid; e < NX * NX; e += TPB) sP[e] = 0.0;
+                __syncthreads();
+                for (int c = tid; c < NX; c += TPB) sPv[c] = GX[N * NX + c];
+                __syncthreads();
+                for (int s = tid; s < P.nxb; s += TPB) {
+                    int c = bnd_state(P, s);
+                    sP[c * NX + c] += Z[N * NH + P.o_xl + s] / S[N * NH + P.o_xl + s] + Z[N * NH + P.o_xu + s] / S[N * NH + P.o_xu + s];
+                }
+            } else {
+                const double *ck = CKP + (size_t)((N - 1 - kst) / NMPC_CKPT_EVERY) * (NX * NX + NX);
+                for (int e = tid; e < NX * NX; e += TPB) sP[e] = ck[e];
+                for (int c = tid; c < NX; c += TPB) sPv[c] = ck[NX * NX + c];
             }
             __syncthreads();
-            for (int k = N - 1; k >= 0; k--) {
+            for (int k = kst; k >= 0; k--) {
+                if (k < kst && (kst - k) % NMPC_CKPT_EVERY == 0) {      // save [P | p] entering this stage (each thread reads back its own words)
+                    double *ck = CKP + (size_t)((N - 1 - k) / NMPC_CKPT_EVERY) * (NX * NX + NX);
+                    for (int e = tid; e < NX * NX; e += TPB) ck[e] = sP[e];
+                    for (int c = tid; c < NX; c += TPB) ck[NX * NX + c] = sPv[c];
+                }
                 // ---- stage data to LDS
                 for (int c = tid; c < NX; c += TPB) { sX[c] = X[k * NX + c]; sCk[c] = Cd[k * NX + c]; }
                 for (int c = tid; c < NU; c += TPB) sU[c] = U[k * NU + c];
@@ -592,7 +608,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                     }
                     __syncthreads();
                 }
-                if (sFail) { ok = false; break; }
+                if (sFail) { ok = false; kf = k; break; }
                 // ---- Y = L^-1 [Qux | qu]: one lane per column, forward substitution
                 for (int c = tid; c <= NX; c += TPB) {
                     double *col = (c < NX) ? (sQux + c) : sQu;
@@ -644,6 +660,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
+            kst = NMPC_RESUME_STAGE(kf, N);
         }
         if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { do_restart(true); iter++; continue; } status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    double *gck = ws + inst * P.stride2 + P.oCKPT;     // [(N-1)/NMPC_CKPT_EVERY + 1][NX + 1][64]  saved cost-to-go of the backward sweep (column-per-lane registers as they are)
     const double *pp = p_in + inst * (2 * NX);
     const double *wi = w0 + inst * (size_t)P.nvar;
     double *wo = w_out + inst * (size_t)P.nvar;
@@ -622,12 +623,17 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
         PROF_T(2);
 
         // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC), column-per-lane
-        // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
+        // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly).
+        // Partial re-factorisation (round 4, include/nmpc_constants.h): the cost-to-go entering every NMPC_CKPT_EVERY-th stage is saved in the
+        // workspace; a rejected pivot at stage kf escalates the shift and resumes the sweep at the saved stage NMPC_RESUME_STAGE(kf, N) — the
+        // stages above keep their factorisation (the pivot rows already stored) and the smaller shift it was made with.
         double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
         int ntry = 0;
         bool ok;
+        int kst = N - 1;        // stage this pass of the sweep starts at
         for (;;) {
             ok = true;
+            int kf = 0;         // stage of the rejected pivot
             if (TPBK == 64 || tid < 64) {          // the sweep is wave 0's (the second wave of the latency shape waits at the barrier below)
             constexpr int TPB = 64;
             if constexpr (RP) {
@@ -675,21 +681,25 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             const bool needxy = (c_state && cd == 2) || (c_ctrl && cd == 0), needth = c_ctrl && cd == 1;
             const int srcA2 = 4 * (needxy ? lb + NC + 3 * cp : (needth ? lb + NC + 3 * cp + 2 : tid));
             const int srcB2 = 4 * (needxy ? lb + NC + 3 * cp + 1 : (needth ? lb + NC + 3 * cp + 2 : tid));
-            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N
+            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N — or, resuming after a rejected pivot, the cost-to-go saved on entry to stage kst
             double m[RR + 1];
-            {
+            static_for<0, NC>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
+            if (kst == N - 1) {
                 const double *pkN = gpack + (size_t)N * G::PACK;
                 const double hdN = c_state ? pkN[G::PK_HD + rcol] : 0.0, gN = c_state ? pkN[G::PK_G + rcol] : 0.0;
-                static_for<0, NC>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
                 static_for<NC, RR>([&](auto rc) { constexpr int r = decltype(rc)::value; m[r] = (c_state && rw == rh && rn == r) ? hdN : 0.0; });
                 m[RR] = gN;
+            } else {
+                const double *ck = gck + (size_t)((N - 1 - kst) / NMPC_CKPT_EVERY) * ((NX + 1) * 64) + tid;
+                static_for<0, NS + 1>([&](auto rc) { constexpr int r = decltype(rc)::value; const double v = ck[r * 64]; m[NC + r] = cvalid ? v : 0.0; });
             }
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
             constexpr bool FULL = PKR * TPB <= RG0 && PKR * TPB <= 2 * G::PACK;
             double pkr[PKR];
 #pragma unroll
-            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)kst * G::PACK + e] : 0.0; }
             double pend_row = 0.0, pend_rhs = 0.0;
+            int ckc = 0;        // stages since the last saved one (the pass starts at a saved stage, or at N-1)
 #if NMPC_COL_DUMMY_ST
             // vmcnt counts loads and stores in issue order.  The wait for a stage's pack (requested at the top of the previous stage) may leave
             // the NU - 1 pivot-row stores issued after that request in flight — but the compiler merges the counter state of the loop's two
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             // acknowledgement latency of the previous stage's last stores.  As many (padding-slot) stores here make the two paths alike.
             static_for<0, NMPC_COL_DUMMY_ST>([&](auto jc) { gkt[(size_t)(N - 1) * G::KTS + decltype(jc)::value * G::LDC + NZ + 1] = 0.0; });
 #endif
-            for (int k = N - 1; k >= 0; k--) {
+            for (int k = kst; k >= 0; k--) {
                 lds_sync<TPB>();
 #pragma unroll
                 for (int t = 0; t < PKR; t++) {
@@ -711,10 +721,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 lds_sync<TPB>();
                 // the lower half stores the pivot rows; every other lane shares the padding slot of the row
                 double *const gkrow = gkt + (size_t)k * G::KTS + ((cvalid && rh == 0) ? rcol : NZ + 1);
-                if (k < N - 1) {
+                if (k < kst) {
                     gkrow[G::KTS + (NU - 1) * G::LDC] = pend_row;
                     if (tid < NU) gkt[(size_t)(k + 1) * G::KTS + tid * G::LDC + NZ] = pend_rhs;
                 }
+                if (ckc == NMPC_CKPT_EVERY) {      // save the cost-to-go entering this stage: state rows and right-hand side as the lanes hold them
+                    ckc = 0;
+                    double *ck = gck + (size_t)((N - 1 - k) / NMPC_CKPT_EVERY) * ((NX + 1) * 64) + tid;
+                    if (cvalid) static_for<0, NS + 1>([&](auto rc) { constexpr int r = decltype(rc)::value; ck[r * 64] = m[NC + r]; });
+                }
+                ckc++;
                 double kO, kA, kB;
                 {
                     kO = c_state ? 1.0 : 0.0; kA = lds_ld(PK, cfA, 0); kB = lds_ld(PK, cfB, 0);
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 });
                 ok = okk;
                 PROF_T(11);
-                if (!ok) break;
+                if (!ok) { kf = k; break; }
                 pend_rhs = rhsv;
                 if (k == 0) {
                     gkrow[(NU - 1) * G::LDC] = pend_row;
@@ -840,14 +856,17 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             const int goff = 8 * (lvalid ? G::PK_G + mycol : G::PK_ZERO);
             const int cfA = 8 * (th_lane ? G::PK_CF + 4 * mrob + 2 : ((is_ctrl && !(ma & 1)) ? G::PK_CF + 4 * mrob : ((is_ctrl && (ma & 1)) ? G::PK_T : G::PK_ZERO)));
             const int cfB = 8 * (th_lane ? G::PK_CF + 4 * mrob + 3 : ((is_ctrl && !(ma & 1)) ? G::PK_CF + 4 * mrob + 1 : G::PK_ZERO));
-            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N: rows NU.. of the state lanes
+            // ---- terminal cost-to-go P_N = diag(hd_N), p_N = g_N: rows NU.. of the state lanes — or the cost-to-go saved on entry to stage kst
             double m[NZ + 1];
-            {
+            static_for<0, NU>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
+            if (kst == N - 1) {
                 const double *pkN = gpack + (size_t)N * G::PACK;
                 const double hdN = is_state ? pkN[G::PK_HD + NU + ms] : 0.0, gN = is_state ? pkN[G::PK_G + NU + ms] : 0.0;
-                static_for<0, NU>([&](auto rc) { m[decltype(rc)::value] = 0.0; });
                 static_for<0, NX>([&](auto rc) { constexpr int r = decltype(rc)::value; m[NU + r] = (is_state && ms == r) ? hdN : 0.0; });
                 m[NZ] = gN;
+            } else {
+                const double *ck = gck + (size_t)((N - 1 - kst) / NMPC_CKPT_EVERY) * ((NX + 1) * 64) + tid;
+                static_for<0, NX + 1>([&](auto rc) { constexpr int r = decltype(rc)::value; const double v = ck[r * 64]; m[NU + r] = is_state ? v : 0.0; });
             }
             // prefetch pack N-1 into registers
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
@@ -856,15 +875,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             constexpr bool FULL = PKR * TPB <= RG0 && PKR * TPB <= 2 * G::PACK;
             double pkr[PKR];
 #pragma unroll
-            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (FULL || e < G::PACK) ? gpack[(size_t)kst * G::PACK + e] : 0.0; }
             // the last pivot row and the right-hand sides of a stage are stored at the top of the NEXT stage, behind the wait for that
             // stage's pack: vmcnt counts loads and stores in order, so a store issued just before the wait adds its whole
             // acknowledgement latency to it
             double pend_row = 0.0, pend_rhs = 0.0;
+            int ckc = 0;        // stages since the last saved one (see the row-paired sweep)
 #if NMPC_COL_DUMMY_ST
             static_for<0, NMPC_COL_DUMMY_ST>([&](auto jc) { gkt[(size_t)(N - 1) * G::KTS + decltype(jc)::value * G::LDC + NZ + 1] = 0.0; });      // (see the row-paired sweep)
 #endif
-            for (int k = N - 1; k >= 0; k--) {
+            for (int k = kst; k >= 0; k--) {
                 // ---- stage pack -> LDS (the inertia shift delta joins the control diagonal here); prefetch the next one
                 lds_sync<TPB>();         // every read of the previous stage's pack is done
 #pragma unroll
@@ -878,10 +898,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 }
                 lds_sync<TPB>();
                 double *const gkrow = gkt + (size_t)k * G::KTS + (lvalid ? mycol : NZ + 1);
-                if (k < N - 1) {
+                if (k < kst) {
                     gkrow[G::KTS + (NU - 1) * G::LDC] = pend_row;
                     if (tid < NU) gkt[(size_t)(k + 1) * G::KTS + tid * G::LDC + NZ] = pend_rhs;
                 }
+                if (ckc == NMPC_CKPT_EVERY) {      // save the cost-to-go entering this stage (state lanes: rows NU.. and the right-hand side)
+                    ckc = 0;
+                    double *ck = gck + (size_t)((N - 1 - k) / NMPC_CKPT_EVERY) * ((NX + 1) * 64) + tid;
+                    if (is_state) static_for<0, NX + 1>([&](auto rc) { constexpr int r = decltype(rc)::value; ck[r * 64] = m[NU + r]; });
+                }
+                ckc++;
                 // coefficients of the <= 3 terms of my column of [B A]: own, gathered A, gathered B
                 double kO, kA, kB;
                 {
@@ -979,7 +1005,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 });
                 ok = okk;
                 PROF_T(11);
-                if (!ok) break;
+                if (!ok) { kf = k; break; }
                 // the right-hand sides of the pivot rows (lanes 0..NU-1 hold them)
                 pend_rhs = rhsv;
                 if (k == 0) {
@@ -1001,6 +1027,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
+            kst = NMPC_RESUME_STAGE(kf, N);        // (wave 0's: the other waves of the latency shape do not sweep)
         }
         if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); iter++; } else status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;

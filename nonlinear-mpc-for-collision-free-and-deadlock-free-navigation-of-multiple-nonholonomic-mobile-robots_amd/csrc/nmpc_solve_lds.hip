@@ -82,6 +82,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    double *gck = ws + inst * P.stride2 + P.oCKPT;     // saved cost-to-go [P | p] of the backward sweep, one slot of (NX + 1) * 64 doubles per NMPC_CKPT_EVERY stages
     const double *pp = p_in + inst * (2 * NX);
     const double *wi = w0 + inst * (size_t)P.nvar;
     double *wo = w_out + inst * (size_t)P.nvar;
@@ -546,19 +547,26 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 
         // ============ B. Riccati sweep with inertia correction (IPOPT alg. IC)
         // first trial: delta = 0, except right after an iteration that needed a shift (then a quarter of that shift directly)
+        // Partial re-factorisation (include/nmpc_constants.h): [P | p] entering every NMPC_CKPT_EVERY-th stage is saved in the workspace; a rejected
+        // pivot at stage kf escalates the shift and resumes at the saved stage NMPC_RESUME_STAGE(kf, N), the stages above keep their factors.
         double delta = need_shift ? fmax(1e-20, 0.25 * delta_last) : 0.0;
         int ntry = 0;
         bool ok;
+        int kst = N - 1;
         for (;;) {
             ok = true;
-            // terminal cost-to-go P_N = diag(hd_N), p_N = g_N
-            {
+            int kf = 0;
+            // terminal cost-to-go P_N = diag(hd_N), p_N = g_N — or the cost-to-go saved on entry to stage kst (Pf and PV are contiguous)
+            if (kst == N - 1) {
                 const double *pkN = gpack + (size_t)N * G::PACK;
                 for (int e = tid; e < NX * NX; e += TPB) {
                     int r = e / NX, c = e - r * NX;
                     Pf[e] = (r == c) ? pkN[G::PK_HD + NU + r] : 0.0;
                 }
                 for (int r = tid; r < NX; r += TPB) PV[r] = pkN[G::PK_G + NU + r];
+            } else {
+                const double *ck = gck + (size_t)((N - 1 - kst) / NMPC_CKPT_EVERY) * ((NX + 1) * 64);
+                for (int e = tid; e < NX * NX + NX; e += TPB) Pf[e] = ck[e];
             }
             // ---- per-element LDS byte offsets (relative to sm): pivot-row entries UR[.][a], UR[.][c]; the three G entries,
             //      the coefficient triple and the Hessian addition of the assembly; the mirror positions of the Schur block
@@ -601,9 +609,13 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             constexpr int PKR = (G::PACK + TPB - 1) / TPB;
             double pkr[PKR];
 #pragma unroll
-            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)(N - 1) * G::PACK + e] : 0.0; }
+            for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; pkr[t] = (e < G::PACK) ? gpack[(size_t)kst * G::PACK + e] : 0.0; }
             lds_sync<TPB>();
-            for (int k = N - 1; k >= 0; k--) {
+            for (int k = kst; k >= 0; k--) {
+                if (k < kst && (kst - k) % NMPC_CKPT_EVERY == 0) {      // save [P | p] entering this stage
+                    double *ck = gck + (size_t)((N - 1 - k) / NMPC_CKPT_EVERY) * ((NX + 1) * 64);
+                    for (int e = tid; e < NX * NX + NX; e += TPB) ck[e] = Pf[e];
+                }
                 // ---- stage pack -> LDS; prefetch the next one
 #pragma unroll
                 for (int t = 0; t < PKR; t++) { int e = tid + t * TPB; if (e < G::PACK) PK[e] = pkr[t]; }
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     }
                 });
                 PROF_T(11);
-                if (!ok) break;
+                if (!ok) { kf = k; break; }
                 // ---- what is left is [P_k | p_k]: back to LDS (both triangles)
                 if (k >= 1) {
 #pragma unroll
@@ -727,6 +739,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : NMPC_SHIFT_ESCALATION;
             if (delta > 1e20) break;
+            kst = NMPC_RESUME_STAGE(kf, N);
         }
         if (!ok) { if (n_cold < NMPC_COLD_RETRIES) { cold_retry(); iter++; } else status = NMPC_STATUS_NUMERIC; break; }
         if (delta > 0.0) delta_last = delta;

@@ -16,6 +16,9 @@ import numpy as np
 from .nlp_ref import NLPConfig
 
 
+CKPT_EVERY, REFACTOR_BACK = 5, 2      # NMPC_CKPT_EVERY, NMPC_REFACTOR_BACK of include/nmpc_constants.h (tests/test_oracle_solver.py checks the header)
+
+
 class Opts:
     tol = 1e-8
     max_iter = 200
@@ -29,6 +32,7 @@ class Opts:
     exact_hessian = True
     reg_where = 'u'       # 'all': delta*I on x and u (IPOPT); 'u': controls only; 'thu': headings and controls
     reg_mode = 'global'   # 'global' (IPOPT alg. IC) or 'stage' (per-stage shift of Quu only)
+    partial_refactor = True   # a rejected pivot resumes the sweep at a saved stage a few stages above (include/nmpc_constants.h) instead of at N-1
     ls_max = 30
     eta = 1e-4
     verbose = False
@@ -255,6 +259,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
         delta = max(1e-20, 0.25 * delta_last) if need_shift else 0.0
         ntry = 0
         nsweep = 0
+        kst = N - 1; kf = 0; ckpt = {}; Ks_prev = ks_prev = None
         while True:
             nsweep += 1
             ok = True
@@ -263,7 +268,12 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
             else: Dx = delta * np.diag(np.tile([0.0, 0.0, 1.0], cfg.m))
             P = Hxx[N] + Dx; pv = gx[N].copy()
             Ks = [None] * N; ks = [None] * N
-            for k in range(N - 1, -1, -1):
+            if o.partial_refactor and kst < N - 1:      # resume from the cost-to-go saved on entry to stage kst (stages above keep their gains)
+                P, pv = ckpt[kst][0].copy(), ckpt[kst][1].copy()
+                Ks[kst + 1:] = Ks_prev[kst + 1:]; ks[kst + 1:] = ks_prev[kst + 1:]
+            for k in range(kst if o.partial_refactor else N - 1, -1, -1):
+                if o.partial_refactor and (N - 1 - k) % CKPT_EVERY == 0:
+                    ckpt[k] = (P.copy(), pv.copy())
                 A, B = AB[k]
                 b = -C[k]
                 Pb = pv + P @ b
@@ -289,7 +299,7 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                     if np.any(np.diag(L) ** 2 < 1e-9 * np.abs(np.diag(Quu))):
                         raise np.linalg.LinAlgError
                   except np.linalg.LinAlgError:
-                    ok = False; break
+                    ok = False; kf = k; break
                 Kk = -np.linalg.solve(Quu, Qux); kk = -np.linalg.solve(Quu, qu)
                 Ks[k], ks[k] = Kk, kk
                 if k >= 1:
@@ -306,6 +316,9 @@ def solve(cfg: NLPConfig, p, w0, opts: Opts = None):
                 delta *= 100.0 if delta_last == 0.0 else 8.0
             if delta > 1e20:
                 break
+            # partial re-factorisation (include/nmpc_constants.h: NMPC_RESUME_STAGE): the nearest saved stage at or above kf + REFACTOR_BACK
+            kst = min(kf + REFACTOR_BACK, N - 1); kst += (N - 1 - kst) % CKPT_EVERY
+            Ks_prev, ks_prev = Ks, ks
         if not ok:
             status = 2; break
         if delta > 0:

@@ -49,16 +49,18 @@ def test_header_symbols_exported(built):
 
 
 def test_forced_build_compiles_every_source(tmp_path):
-    """NMPC_FORCE_BUILD=1: __graft_entry__.build() must run hipcc on every source (not reuse the in-tree binary) and say so — the
-    check that the tree builds from scratch here, independent of whatever library travelled with the snapshot.  Runs in a child
-    process (the parent may hold the library open) and restores nothing: the rebuilt library has the same source hash."""
-    env = dict(os.environ, NMPC_FORCE_BUILD="1")
+    """NMPC_FORCE_BUILD=1: __graft_entry__.build() must run hipcc on every source (not reuse a binary) and say so — the check that the tree
+    builds from scratch here, independent of whatever library travelled with the snapshot.  Runs in a child process and builds into a
+    temporary directory (NMPC_LIBDIR / NMPC_OBJDIR / NMPC_SO): the in-tree lib/libnmpc_hip.so that this session and any
+    other process have mapped is not replaced; the child loads the fresh library and checks every declared export."""
+    env = dict(os.environ, NMPC_FORCE_BUILD="1", NMPC_LIBDIR=str(tmp_path), NMPC_OBJDIR=str(tmp_path / "obj"), NMPC_SO=str(tmp_path / "libnmpc_hip.so"))
     out = subprocess.check_output([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, env=env, text=True, stderr=subprocess.STDOUT)
-    assert "[nmpc build] compiled libnmpc_hip.so" in out and "build(): compiled" in out, out
-    import importlib
+    assert "[nmpc build] compiled libnmpc_hip.so" in out and "build(): compiled" in out and str(tmp_path) in out, out
+    import importlib, json
     bld = importlib.import_module("nmpc_amd.build")
-    info = bld.last_build_info()
-    assert info["mode"] == "compiled" and info["src_hash"] == bld.source_hash() == bld.built_hash() and info["seconds"] > 5.0, info
+    info = json.load(open(tmp_path / "build_info.json"))
+    assert info["mode"] == "compiled" and info["src_hash"] == bld.source_hash() and info["seconds"] > 5.0 and info["hipcc"], info
+    assert ("src=" + bld.source_hash()).encode() in open(tmp_path / "libnmpc_hip.so", "rb").read()
 
 
 def test_sizes_defaults_and_config_mirror(built):
