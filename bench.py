@@ -46,36 +46,62 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (MI355X_MICROARC
 HBM_PEAK_GBS = 8000.0
 
 
-def _composite(R):
-    """six robots (C6 literals) + 8 circular obstacles in [-1.5, 1.5]^2, radii U[0.125, 0.2], rob_dim 0.2, margin 0.1, N = 25."""
+# ---- synthetic workload of SURVEY.md 8(d), built from the PRODUCT side (nmpc_amd presets): nothing here imports oracle/ or tests/
+SEED0 = 20210141
+# the scripts' literal start / goal sets, instance 0 of their batches (C6:364-388, C2:213-224); tests/test_abi_host.py checks them against the oracle's table
+C2_LITERAL = ([-0.7112, -0.7112, 0.785, 0.7112, 0.7112, -2.356], [0.7112, 0.7112, 0.785, -0.7112, -0.7112, -2.356])
+C6_LITERAL = ([0.7, 0.4, -2.618, 0.0, 0.8, -1.57, -0.7, 0.4, -0.523, -0.7, -0.4, 0.523, 0.0, -0.8, 1.57, 0.7, -0.4, 2.618],
+              [-0.7, -0.4, -2.618, 0.0, -0.8, -1.57, 0.7, -0.4, -0.523, 0.7, 0.4, 0.523, 0.0, 0.8, 1.57, -0.7, 0.4, 2.618])
+
+
+def composite_obstacles():
+    """8 circular obstacles in [-1.5, 1.5]^2, radii U[0.125, 0.2] (BASELINE.json configs[4]: synthetic, no reference script)."""
     rng = np.random.default_rng(7)
-    c = R.cfg_six(25); c.rob_dim = 0.2; c.margin = 0.1
-    c.obstacles = [(float(x), float(y), float(r)) for x, y, r in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
-    return c
+    return [(float(x), float(y), float(r)) for x, y, r in zip(rng.uniform(-1.5, 1.5, 8), rng.uniform(-1.5, 1.5, 8), rng.uniform(0.125, 0.2, 8))]
 
 
 def workload(name: str):
-    """(oracle NLPConfig, batch per GPU, config index) — literals from the reference scripts."""
-    from oracle import nlp_ref as R
+    """(product ProblemConfig, batch per GPU, config index) — literals from the reference scripts (nmpc_amd presets cite the lines)."""
+    import nmpc_amd
     table = {
-        "two": (R.cfg_two(20), 4096, 1),            # north_star: N_robots=2, N=20, batch 4096 (BASELINE configs[1] quotes 1024)
-        "six": (R.cfg_six(20), 4096, 2),            # BASELINE configs[2], the headline
-        "ten20": (R.cfg_ten(20), 4096, 3),          # north_star: N_robots=10, N=20, batch 4096 (the file's own horizon)
-        "ten": (R.cfg_ten(30), 512, 3),             # BASELINE configs[3]: N=30, 512 per GPU
-        "composite": (_composite(R), 1024, 4),      # BASELINE.json configs[4]: synthetic, no reference script (SURVEY.md 0, mismatch 2)
+        "two": (lambda: nmpc_amd.centralized_two_robots(N=20), 4096, 1),            # north_star: N_robots=2, N=20, batch 4096 (BASELINE configs[1] quotes 1024)
+        "six": (lambda: nmpc_amd.centralized_six_robots(N=20), 4096, 2),            # BASELINE configs[2], the headline
+        "ten20": (lambda: nmpc_amd.ten_robots_collision_avoidance(N=20), 4096, 3),  # north_star: N_robots=10, N=20, batch 4096 (the file's own horizon)
+        "ten": (lambda: nmpc_amd.ten_robots_collision_avoidance(N=30), 512, 3),     # BASELINE configs[3]: N=30, 512 per GPU
+        "composite": (lambda: nmpc_amd.six_robots_eight_obstacles(N=25, obstacles=composite_obstacles()), 1024, 4),   # BASELINE configs[4] (SURVEY.md 0, mismatch 2)
     }
-    return table[name]
+    mk, B, cidx = table[name]
+    return mk(), B, cidx
+
+
+def _sample_points(rng, m, dsep, lim=2.0, obstacles=(), clear=0.0):
+    pts = []
+    while len(pts) < m:
+        c = rng.uniform(-lim, lim, 2)
+        if all(np.hypot(*(c - q)) >= dsep for q in pts) and all(np.hypot(c[0] - ox, c[1] - oy) >= clear + orad for (ox, oy, orad) in obstacles):
+            pts.append(c)
+    return np.array(pts)
+
+
+def instance(rng, cfg):
+    """p = [x0; xs] of SURVEY.md 8(d): starts / goals uniform in [-2, 2]^2 with pairwise distance >= dmin + 0.1 (and clear of every obstacle), theta uniform."""
+    m = cfg.m
+    dsep = cfg.dmin + 0.1
+    clear = cfg.rob_dim + cfg.margin + 0.05
+    s = _sample_points(rng, m, dsep, obstacles=cfg.obstacles, clear=clear)
+    g = _sample_points(rng, m, dsep, obstacles=cfg.obstacles, clear=clear)
+    x0 = np.concatenate([s, rng.uniform(-np.pi, np.pi, (m, 1))], axis=1).reshape(-1)
+    xs = np.concatenate([g, rng.uniform(-np.pi, np.pi, (m, 1))], axis=1).reshape(-1)
+    return np.concatenate([x0, xs])
 
 
 # global batch of --scaling strong: what BASELINE.json quotes for the workload (configs[1..4])
 STRONG_TOTAL = {"two": 1024, "six": 4096, "ten20": 4096, "ten": 4096, "composite": 8192}
-# committed rocprofv3 summaries (tools/collect_profiles.sh + tools/summarize_profiles.py) per workload: profiles/<dir>/hbm_traffic.json
-PROFILE_DIR = {"six": "current", "two": "current_two", "ten20": "current_ten20", "ten": "current_ten", "composite": "current_composite", "lidar": "current_lidar"}
 
 
 def algorithmic_flops_per_iter(cfg) -> float:
     """F_kkt + F_asm per interior-point iteration (dense Riccati count)."""
-    nx, nu, N, m, M, K = cfg.nx, cfg.nu, cfg.N, cfg.m, cfg.M, cfg.K
+    nx, nu, N, m, M, K = cfg.nx, cfg.nu, cfg.N, cfg.m, cfg.M, len(cfg.obstacles)
     f_kkt = N * (7.0 / 3.0 * nx ** 3 + 4.0 * nx ** 2 * nu + 2.0 * nx * nu ** 2 + nu ** 3 / 3.0)
     f_asm = N * (22.0 * m + 14.0 * M + 16.0 * m * K)
     return f_kkt + f_asm
@@ -83,7 +109,7 @@ def algorithmic_flops_per_iter(cfg) -> float:
 
 def algorithmic_bytes_per_solve(cfg) -> float:
     """minimal fp64 I/O of one solve."""
-    return 8.0 * (2 * cfg.nx + 2 * cfg.n_var) + 16.0 + 8.0 * 3 * cfg.K
+    return 8.0 * (2 * cfg.nx + 2 * cfg.n_var) + 16.0 + 8.0 * 3 * len(cfg.obstacles)
 
 
 def _free_port() -> int:
@@ -102,28 +128,27 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def make_batch(name, rank, batch=0, shard=None):
-    """shard = (lo, hi): the instances [lo, hi) of ONE global batch of `batch` instances drawn from the rank-0 stream (strong scaling);
-    otherwise every rank draws its own `batch` instances (weak scaling)."""
+def make_batch(name, rank, batch=0, shard=None, max_iter=2000):
+    """(product config, B, P, W0).  shard = (lo, hi): the instances [lo, hi) of ONE global batch of `batch` instances drawn from the rank-0
+    stream (strong scaling); otherwise every rank draws its own `batch` instances (weak scaling)."""
     import nmpc_amd
-    from tests import helpers as Hh
-    from oracle import nlp_ref as R
-    ocfg, B, cidx = workload(name)
+    cfg, B, cidx = workload(name)
+    cfg.max_iter = max_iter
     if batch:
         B = batch
     # synthetic instances of SURVEY.md §8(d); each rank draws its own shard (seed + rank stream)
-    rng = np.random.Generator(np.random.PCG64([Hh.SEED0 + cidx, 0 if shard else rank]))
-    P = np.stack([Hh.instance(rng, ocfg) for _ in range(B)])
+    rng = np.random.Generator(np.random.PCG64([SEED0 + cidx, 0 if shard else rank]))
+    P = np.stack([instance(rng, cfg) for _ in range(B)])
     # SURVEY.md 8(d): instance 0 of every batch is the reference's literal start/goal set (C6:364-388, C2:213-224); the literal
     # x0 of the ten-robot script has coincident robots (status 3 by construction), so that workload keeps its drawn instance
-    lit = {"six": (R.C6_START, R.C6_GOAL), "two": (R.C2_START, R.C2_GOAL)}.get(name)
+    lit = {"six": C6_LITERAL, "two": C2_LITERAL}.get(name)
     if lit is not None:
-        P[0] = np.concatenate(lit)
-    W0 = np.stack([R.cold_start(ocfg, p[: ocfg.nx]) for p in P])
+        P[0] = np.concatenate([np.array(lit[0]), np.array(lit[1])])
+    W0 = np.stack([nmpc_amd.cold_start(cfg, p[: cfg.nx]) for p in P])
     if shard:
         lo, hi = shard
-        return ocfg, hi - lo, P[lo:hi], W0[lo:hi]
-    return ocfg, B, P, W0
+        return cfg, hi - lo, P[lo:hi], W0[lo:hi]
+    return cfg, B, P, W0
 
 
 def timed_solves(solver, dP, dW0, steps, warmup, barrier):
@@ -146,40 +171,48 @@ def timed_solves(solver, dP, dW0, steps, warmup, barrier):
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
 
 
-def roofline_block(ocfg, B, sum_iters, kern_ms, lib_version, kernel_id, wname="six"):
-    fl_iter = algorithmic_flops_per_iter(ocfg)
+FP64_SUSTAINED_TFLOPS = 47.7   # measured on this pool with every SIMD busy (tools/valu_probe.hip: the box clocks ~1.45 GHz under sustained fp64 load, not the 2.4 GHz of the peak)
+ROOFLINE_NOTE = ("roofline blocks: compute/latency-bound fp64 kernels with zero MFMA instructions, priced against the fp64 VECTOR peak 78.6 TFLOP/s (= the fp64 matrix "
+                 "peak on MI355X); achieved = algorithmic flops iters*(F_kkt+F_asm) of SURVEY.md 8(d) / kernel time from HIP events on the launch stream; frac_sustained = "
+                 "achieved / 47.7 TFLOP/s (what tools/valu_probe.hip sustains on this pool); traffic = PMC bytes per iteration of the committed profile "
+                 "(2*FETCH_SIZE + WRITE_SIZE, KB units, separate passes) x iterations of this launch, null unless the profile was taken from this very build, batch and kernel shape")
+
+
+def profile_dir(wname, B):
+    """committed rocprofv3 summaries (tools/collect_profiles.sh + tools/summarize_profiles.py) per workload AND batch: profiles/<dir>/hbm_traffic.json"""
+    base = {"six": "current", "two": "current_two", "ten20": "current_ten20", "ten": "current_ten", "composite": "current_composite", "lidar": "current_lidar"}[wname]
+    default_b = {"six": 4096, "two": 4096, "ten20": 4096, "ten": 512, "composite": 1024, "lidar": 4096}[wname]
+    return base if B == default_b else "%s_b%d" % (base, B)
+
+
+def roofline_block(cfg, B, sum_iters, kern_ms, lib_version, kernel_id, wname="six"):
+    fl_iter = algorithmic_flops_per_iter(cfg)
     flops_launch = float(sum_iters) * fl_iter
     achieved = flops_launch / (kern_ms * 1e-3) / 1e12
     # the kernel nmpc_solve_batch picked for this team size and batch, as the library reports it (nmpc_query):
     # 3 column-per-lane, throughput shape (one wavefront per instance); 4 the same kernel's latency shape (two wavefronts per instance, four
     # where the library's rule says so: the composite); 2 element-per-lane; 1 HBM-resident fallback
-    kname = {3: "nmpc::solve_col_kernel<%d,...,64>", 4: "nmpc::solve_col_kernel<%d,...,128|256> (latency shape)", 5: "nmpc::solve_col_kernel<%d,...,256>",
-             2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % ocfg.m
+    kname = {3: "nmpc::solve_col_kernel<%d,...,64>", 4: "nmpc::solve_col_kernel<%d,...,128|256> (latency shape)",
+             2: "nmpc::solve_lds_kernel<%d,...>", 1: "nmpc::solve_kernel<%d,...>"}.get(kernel_id, "nmpc::solve_?_kernel<%d>") % cfg.m
     rl = {"bound": "fp64-valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
-          "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(ocfg) * B,
-          "hbm_frac_of_algorithmic_bytes": algorithmic_bytes_per_solve(ocfg) * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-          "note": "compute/latency-bound fp64 kernel with zero MFMA instructions: priced against the fp64 VECTOR peak 78.6 TFLOP/s "
-                  "(= the fp64 matrix peak on MI355X); algorithmic flops = iters*(F_kkt+F_asm) of SURVEY.md 8(d)"}
-    # HBM traffic of the solve kernel: FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 --pmc passes (profiles/current, collected
-    # with tools/collect_profiles.sh on the default command, corrected as MI355X_MICROARCH.md prescribes), stored per interior-point
-    # iteration and scaled by the iterations of THIS launch.  The profile is stamped with the source hash of the library it was
-    # taken from: null unless this run's library is that very build and the workload matches.
+          "frac": achieved / FP64_PEAK_TFLOPS, "frac_sustained": achieved / FP64_SUSTAINED_TFLOPS, "traffic": None, "flops_per_launch": flops_launch, "kernel_ms": kern_ms,
+          "algorithmic_bytes_per_launch": algorithmic_bytes_per_solve(cfg) * B}
+    # HBM traffic of the solve kernel from the committed PMC passes; bytes per iteration and instance DO depend on the batch (cache residency
+    # of the per-instance workspaces) and on the kernel shape (the latency shape keeps the slacks and duals in LDS): only a profile taken from
+    # this build, at this batch and in this shape is used (ADVICE r3)
     try:
-        pdir = PROFILE_DIR.get(wname, "current")
+        pdir = profile_dir(wname, B)
         tj = json.load(open(os.path.join(ROOT, "profiles", pdir, "hbm_traffic.json")))
         same_lib = tj.get("library_src_hash") and ("src=" + tj["library_src_hash"]) in lib_version
-        if same_lib and tj["workload"].get("m") == ocfg.m and tj["workload"].get("N") == ocfg.N:
-            # bytes per interior-point iteration and instance do not depend on the batch size (every instance works on its own workspace); an
-            # entry at another batch than the profile's says so
+        wl = tj["workload"]
+        if same_lib and wl.get("m") == cfg.m and wl.get("N") == cfg.N and wl.get("batch_per_gpu") == B and wl.get("kernel_id", kernel_id) == kernel_id:
             rl["traffic"] = tj["hbm_bytes_per_iteration"] * float(sum_iters)
-            rl["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration (2*FETCH_SIZE + WRITE_SIZE, KB units) x iterations of this launch%s" % (
-                pdir, tj["library_src_hash"], "" if tj["workload"].get("batch_per_gpu") == B else " (profile taken at batch %s)" % tj["workload"].get("batch_per_gpu"))
             rl["traffic_GBps"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9
+            rl["traffic_source"] = "profiles/%s@src=%s" % (pdir, tj["library_src_hash"])
         else:
-            rl["traffic_source"] = "null: profiles/%s/hbm_traffic.json was taken from another build or workload (src=%s)" % (pdir, tj.get("library_src_hash"))
+            rl["traffic_source"] = "null: profiles/%s is of another build, batch or kernel shape (src=%s)" % (pdir, tj.get("library_src_hash"))
     except (OSError, KeyError, ValueError):
-        pass
+        rl["traffic_source"] = "null: no committed profile for this workload and batch"
     return rl
 
 
@@ -204,7 +237,6 @@ def main():
     import torch
     import torch.distributed as dist
     import nmpc_amd
-    from tests import helpers as Hh
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,11 +267,11 @@ def main():
 
     if args.scaling == "strong":
         total = args.batch_total or STRONG_TOTAL[args.workload]
-        ocfg, B, P, W0 = make_batch(args.workload, rank, total, shard=nmpc_amd.shard_range(total, rank, world))
+        cfg, B, P, W0 = make_batch(args.workload, rank, total, shard=nmpc_amd.shard_range(total, rank, world), max_iter=args.max_iter)
     else:
         total = None
-        ocfg, B, P, W0 = make_batch(args.workload, rank, args.batch)
-    cfg = Hh.to_product_cfg(ocfg, max_iter=args.max_iter)
+        cfg, B, P, W0 = make_batch(args.workload, rank, args.batch, max_iter=args.max_iter)
+    nM, nK = cfg.M, len(cfg.obstacles)
     solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
     kernel_id = int(solver.kernel_for_batch(B))
     dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
@@ -283,17 +315,18 @@ def main():
     value = total_solves / t_max
     sum_iters = float(allst[:, 1].sum())
     out = {
-        "metric": "NMPC solves/sec (batched swarms), N_robots=%d, N=%d" % (ocfg.m, ocfg.N),
+        "metric": "NMPC solves/sec (batched swarms), N_robots=%d, N=%d" % (cfg.m, cfg.N),
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d per GPU, cold start" %
-                   (args.workload, ocfg.m, ocfg.N, ocfg.M, ocfg.K, B), "m": ocfg.m, "N": ocfg.N, "batch_per_gpu": B, "batch_total": int(n_inst), "max_iter": args.max_iter, "tol": cfg.tol,
-                   "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
+                   (args.workload, cfg.m, cfg.N, nM, nK, B), "m": cfg.m, "N": cfg.N, "batch_per_gpu": B, "batch_total": int(n_inst), "max_iter": args.max_iter, "tol": cfg.tol,
+                   "kernel_id": kernel_id, "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
         "library": lib_version,
         "solve_stats": {"mean_iters": sum_iters / n_inst, "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / n_inst, "max_kkt_converged": float(allst[:, 4].max())},
-        "roofline": roofline_block(ocfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version, kernel_id, args.workload),
+        "roofline": roofline_block(cfg, B, float(allst[0, 1]), float(allst[0, 5]), lib_version, kernel_id, args.workload),
+        "note": ROOFLINE_NOTE,
     }
     if world > 1:
         per_rank_bytes = B * (cfg.n_var * 8 + 8)
@@ -321,13 +354,13 @@ def main():
                               "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
                               "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
                               "converged_frac": float((conv == 0).mean()),
-                              "note": "warm-started receding horizon, one nmpc_step_batch per period: solve (dispatch order = previous period's iteration counts, longest first), guess shift, plant step x0+T f(x0,u0) and the next order, all on the device"}
+                              "note": "warm receding horizon, one nmpc_step_batch per period (solve in longest-first order, shift, plant step, next order: all on the device)"}
         torch.cuda.synchronize(); t3 = time.perf_counter()
         rh = solver.solve_batch(P, W0)
         xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()
         t_h = time.perf_counter() - t3
         out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
-                               "note": "same cold batch with pageable host numpy buffers at the boundary: H2D of p and w0, solve, D2H of w/status"}
+                               "note": "same cold batch, pageable host buffers at the boundary (H2D p, w0; D2H w, status): PCIe-inclusive, never `value`"}
     # north-star sweep: N_robots in {2, 6, 10}, N=20, batch 4096 (+ BASELINE configs[3] and [4]); one warm-up + two timed launches each
     do_sweep = args.sweep if args.sweep >= 0 else (1 if (world == 1 and args.workload == "six" and not args.batch) else 0)
     if world == 1 and do_sweep:
@@ -336,34 +369,34 @@ def main():
         # (workload, batch; 0 = the workload's own): the four north-star shapes, then ten robots at N=30 with the whole BASELINE batch on one
         # GPU (what strong sharding to 512 per GPU is compared with) and six robots at B=16384, where the launch outgrows its longest solve
         for name, bsz in (("two", 0), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):
-            oc2, B2, P2, W2 = make_batch(name, 0, bsz)
-            c2 = Hh.to_product_cfg(oc2, max_iter=args.max_iter)
+            c2, B2, P2, W2 = make_batch(name, 0, bsz, max_iter=args.max_iter)
             s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
             d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)
             it2 = r2["iters"].cpu().numpy(); st2 = r2["status"].cpu().numpy()
-            out["sweep"].append({"workload": "%s: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d, cold start" % (name, oc2.m, oc2.N, oc2.M, oc2.K, B2),
-                                 "m": oc2.m, "N": oc2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
+            out["sweep"].append({"workload": "%s: m=%d, N=%d, K=%d, batch=%d, cold" % (name, c2.m, c2.N, len(c2.obstacles), B2),
+                                 "m": c2.m, "N": c2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
                                  "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
                                  "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
-                                 "roofline": roofline_block(oc2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
+                                 "roofline": roofline_block(c2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
             del s2
             torch.cuda.empty_cache()
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
     # 13 states, N=100, Nc=50; SURVEY.md 0 mismatch 2): one wavefront per instance, the instance's workspace lives in HBM/L2
     if world == 1 and do_sweep:
-        from oracle import lidar_ref as LR
-        lc = LR.lidar_v4()
+        lc = nmpc_amd.lidar_v4()
         Bl = 4096
-        rngl = np.random.Generator(np.random.PCG64(Hh.SEED0 + 5))
-        Pl, Wl = [], []
+        rngl = np.random.Generator(np.random.PCG64(SEED0 + 5))
+        poses, worlds, goals = [], [], []
         for _ in range(Bl):
-            pose = np.array([rngl.uniform(0.0, 0.15), rngl.uniform(0.0, 0.15), rngl.uniform(0.4, 1.1)])
-            world_ = [(float(rngl.uniform(0.8, 2.6)), float(rngl.uniform(0.3, 2.4)), float(rngl.uniform(0.15, 0.3))) for _ in range(3)]
-            scan = LR.scan_of_world(pose, world_, lc.R)
-            Pl.append(LR.make_p(lc, pose, np.array([3.0, 2.5, 0.0]) + rngl.uniform(-0.3, 0.3, 3), scan)); Wl.append(LR.cold_start(lc, np.concatenate([pose, scan])))
-        Pl = np.stack(Pl); Wl = np.stack(Wl)
-        lbx, ubx, _, _ = LR.bounds(lc)
-        ls = nmpc_amd.LidarSolver(nmpc_amd.lidar_v4(), lbx=lbx, ubx=ubx, max_batch=Bl)
+            poses.append([rngl.uniform(0.0, 0.15), rngl.uniform(0.0, 0.15), rngl.uniform(0.4, 1.1)])
+            worlds.append([(float(rngl.uniform(0.8, 2.6)), float(rngl.uniform(0.3, 2.4)), float(rngl.uniform(0.15, 0.3))) for _ in range(3)])
+            goals.append(np.array([3.0, 2.5, 0.0]) + rngl.uniform(-0.3, 0.3, 3))
+        poses = np.array(poses); worlds = np.array(worlds)
+        lbx, ubx = lc.bounds()[:2]
+        ls = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
+        scans = ls.scan_batch(poses, worlds).cpu().numpy()          # the synthetic LaserScan of V4:29-36, on the device (nmpc_lidar_scan_batch)
+        Pl = np.stack([nmpc_amd.lidar_params(lc, poses[b], goals[b], scans[b]) for b in range(Bl)])
+        Wl = np.stack([nmpc_amd.lidar_cold_start(lc, np.concatenate([poses[b], scans[b]])) for b in range(Bl)])
         dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
         itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
         alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
@@ -382,24 +415,25 @@ def main():
                                           "flops_per_iteration": fl_iter_l, "flops_per_launch": fl_iter_l * float(itl.sum()),
                                           "algorithmic_bytes_per_launch": alg_bytes,
                                           "hbm_frac_of_algorithmic_bytes": alg_bytes / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "note": "algorithmic flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5), priced against "
-                                                  "the fp64 vector peak like the main kernel; the kernel is latency-bound (two serial recursions over 100 stages per "
-                                                  "iteration, one wavefront per instance): the fraction says how far"}})
+                                          "frac_sustained": ach / FP64_SUSTAINED_TFLOPS,
+                                          "note": "flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5); latency-bound: one wavefront per instance, serial recursions over 100 stages"}})
         # PMC traffic of the LIDAR kernel (profiles/current_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
         try:
-            tjl = json.load(open(os.path.join(ROOT, "profiles", PROFILE_DIR["lidar"], "hbm_traffic.json")))
+            pdl = profile_dir("lidar", Bl)
+            tjl = json.load(open(os.path.join(ROOT, "profiles", pdl, "hbm_traffic.json")))
             rll = out["sweep"][-1]["roofline"]
             if tjl.get("library_src_hash") and ("src=" + tjl["library_src_hash"]) in lib_version and tjl["workload"].get("batch_per_gpu") == Bl:
                 rll["traffic"] = tjl["hbm_bytes_per_iteration"] * float(itl.sum())
                 rll["traffic_GBps"] = rll["traffic"] / (kl * 1e-3) / 1e9
-                rll["traffic_source"] = "profiles/%s/hbm_traffic.json@src=%s: PMC bytes per iteration x iterations of this launch" % (PROFILE_DIR["lidar"], tjl["library_src_hash"])
+                rll["traffic_source"] = "profiles/%s@src=%s" % (pdl, tjl["library_src_hash"])
             else:
-                rll["traffic_source"] = "null: profiles/%s/hbm_traffic.json was taken from another build or batch (src=%s)" % (PROFILE_DIR["lidar"], tjl.get("library_src_hash"))
+                rll["traffic_source"] = "null: profiles/%s is of another build or batch (src=%s)" % (pdl, tjl.get("library_src_hash"))
         except (OSError, KeyError, ValueError):
             pass
         # CPU baseline of the LIDAR workload: the C oracle (oracle/lidar_oracle.c, OpenMP one instance per thread) on a bounded sample
         if args.cpu_sample != 0:
-            from oracle import oracle_lib as OL
+            from oracle import oracle_lib as OL, lidar_ref as LR
+            lc = LR.lidar_v4()          # the checker's own definition of the same literals
             coresl = OL.max_threads()
             nl = min(Bl, 4 * coresl)
             OL.lidar_solve_batch(lc, Pl[:coresl], Wl[:coresl], lbx=lbx, ubx=ubx)
@@ -417,6 +451,8 @@ def main():
     # CPU baseline: the C oracle on this box's host cores, bounded sample of the same workload
     if world == 1 and args.cpu_sample != 0:
         from oracle import oracle_lib as O
+        from tests import helpers as Hh
+        ocfg = Hh.to_oracle_cfg(cfg)
         cores = O.max_threads()
         n = args.cpu_sample if args.cpu_sample > 0 else min(B, 16 * cores)
         oc = O.make_config(ocfg, max_iter=args.max_iter)
@@ -431,6 +467,20 @@ def main():
         # the GPU results of those instances agree with the oracle (same-basin fraction reported, not asserted here)
         dw = np.max(np.abs(r["x"][:n].cpu().numpy() - ref["x"]), axis=1)
         out["cpu_baseline"]["same_basin_frac_vs_gpu"] = float((dw <= 1e-6).mean())
+    # the extra CPU row of BASELINE.md 3 / SURVEY.md 8(d): nlpsol('ipopt') on the identical NLP built through the CasADi API by the build's own
+    # generator (oracle/casadi_probe.py) — only if casadi happens to be importable on this box; the record says which
+    if world == 1 and args.cpu_sample != 0:
+        from oracle import casadi_probe as CP
+        from tests import helpers as Hh
+        ok_ca, what_ca = CP.available()
+        if not ok_ca:
+            out["casadi"] = "not importable on this box (%s): no CasADi/IPOPT row, parity stays unpinned" % what_ca
+        else:
+            n_ca = min(B, 8)
+            ref_ca = CP.solve(Hh.to_oracle_cfg(cfg), P[:n_ca], W0[:n_ca])
+            dca = np.max(np.abs(r["x"][:n_ca].cpu().numpy() - ref_ca["x"]), axis=1)
+            out["casadi"] = {"version": what_ca, "value": 1.0 / float(ref_ca["seconds"].mean()), "unit": "solves/s", "cores": 1, "kind": "casadi-ipopt (own generator, C6:345 options)",
+                             "sample": "first %d instances, one thread" % n_ca, "same_point_frac_vs_gpu": float((dca <= 1e-6).mean()), "return_status": sorted(set(ref_ca["return_status"]))}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

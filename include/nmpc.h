@@ -112,9 +112,10 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
 
 /*
  * Facts about a handle.  Returns the value, or a negative NMPC_E_* code.
- *   NMPC_QUERY_KERNEL_FOR_BATCH  arg = B: the solve kernel nmpc_solve_batch launches for a batch of B (1 / 2 / 3 / 4 as in nmpc_options_t)
+ *   NMPC_QUERY_KERNEL_FOR_BATCH  arg = B: the solve kernel nmpc_solve_batch launches for a batch of B: 1 / 2 / 3 as in nmpc_options_t, 4 = the
+ *                                column kernel's latency shape (two OR four wavefronts per instance: 5 is a pin, never an answer)
  *   NMPC_QUERY_WORKSPACE_BYTES   device workspace held by the handle (same as nmpc_workspace_bytes)
- *   NMPC_QUERY_LDS_BYTES         arg = B: dynamic LDS per swarm instance of that kernel (0 for the HBM-resident kernel's fixed carve-up)
+ *   NMPC_QUERY_LDS_BYTES         arg = B: dynamic LDS per swarm instance of the kernel an UNORDERED call of B gets (0 for the HBM-resident kernel's fixed carve-up)
  *   NMPC_QUERY_MAX_BATCH         the max_batch the handle was created for
  *   NMPC_QUERY_KERNEL_FOR_ORDERED_BATCH  arg = B: as NMPC_QUERY_KERNEL_FOR_BATCH for a call that carries a dispatch-order hint
  *                                (nmpc_solve_batch_ordered, nmpc_step_batch): the latency shape is kept for larger batches then
@@ -182,6 +183,9 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
  *   order  [B] int32   in: dispatch order of this period (a permutation of 0..B-1; anything else is detected and ignored);
  *                      out: the instances sorted by this period's iteration counts, longest first — the hint for the next call.
  *                      May be NULL (index order, no hint produced).  A caller's first call passes the identity.
+ * Failed solves: an instance that ends with NMPC_STATUS_NUMERIC (2: the iterate may be non-finite) or NMPC_STATUS_INFEASIBLE_X0 (3) keeps its
+ * x0 and its guess — its rows of p and w are NOT overwritten (w_sol holds what the solve returned); statuses 1 and 4 return a finite last
+ * iterate and are shifted like a converged one, as the scripts do with any IPOPT return.
  */
 int32_t nmpc_step_batch(nmpc_handle_t *h, int32_t B, double *p, double *w, double *w_sol, double *obj, int32_t *status, int32_t *iters,
                         double *kkt, int32_t *order, void *stream);

@@ -21,7 +21,7 @@ ERRORS = {-1: "NMPC_E_ARG", -2: "NMPC_E_UNSUPPORTED", -3: "NMPC_E_HIP", -4: "NMP
 LIDAR_EXPORTS = ["nmpc_lidar_n_var", "nmpc_lidar_n_g", "nmpc_lidar_n_p", "nmpc_lidar_create", "nmpc_lidar_destroy", "nmpc_lidar_solve_batch",
                  "nmpc_lidar_eval_batch", "nmpc_lidar_shift_batch", "nmpc_lidar_scan_batch", "nmpc_lidar_plant_batch"]
 DEBUG_EXPORTS = ["nmpc_debug_profile", "nmpc_debug_trace", "nmpc_debug_trace2", "nmpc_debug_workspace"]      # include/nmpc_debug.h
-QUERY_KERNEL_FOR_BATCH, QUERY_WORKSPACE_BYTES, QUERY_LDS_BYTES, QUERY_MAX_BATCH = 1, 2, 3, 4
+QUERY_KERNEL_FOR_BATCH, QUERY_WORKSPACE_BYTES, QUERY_LDS_BYTES, QUERY_MAX_BATCH, QUERY_KERNEL_FOR_ORDERED_BATCH = 1, 2, 3, 4, 5      # NMPC_QUERY_* of include/nmpc.h
 EXPORTS = ["nmpc_n_var", "nmpc_n_g", "nmpc_n_p", "nmpc_config_default", "nmpc_create", "nmpc_create_opts", "nmpc_query", "nmpc_destroy",
            "nmpc_workspace_bytes", "nmpc_solve_batch", "nmpc_solve_batch_ordered", "nmpc_step_batch", "nmpc_eval_batch", "nmpc_shift_batch", "nmpc_odometry_batch", "nmpc_version"]
 

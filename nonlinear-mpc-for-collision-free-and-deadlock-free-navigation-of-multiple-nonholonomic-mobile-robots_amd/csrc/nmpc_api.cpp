@@ -27,6 +27,7 @@ struct nmpc_handle {
     int lat_waves;       // 0: two or four wavefronts by the rule of lat_waves_shape(); 2 / 4: pinned (nmpc_options_t.kernel = 4 / 5)
     int32_t *ord_chk;    // [max_batch + 1] permutation check of a dispatch-order hint: counts, then the "bad" flag
     int32_t *it_buf;     // [max_batch] iteration counts of nmpc_step_batch when the caller passes iters == NULL
+    int32_t *st_buf;     // [max_batch] statuses of nmpc_step_batch when the caller passes status == NULL (the in-place update skips failed instances)
 };
 
 // makes the handle's device current for one call and restores the caller's on return
@@ -160,6 +161,7 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
     if (hipMalloc((void **)&h->ord_chk, sizeof(int32_t) * ((size_t)max_batch + 1)) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); free(h); return NMPC_E_NOMEM; }
     (void)hipMemset(h->ord_chk, 0, sizeof(int32_t) * ((size_t)max_batch + 1));
     if (hipMalloc((void **)&h->it_buf, sizeof(int32_t) * (size_t)max_batch) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); (void)hipFree(h->ord_chk); free(h); return NMPC_E_NOMEM; }
+    if (hipMalloc((void **)&h->st_buf, sizeof(int32_t) * (size_t)max_batch) != hipSuccess) { (void)hipFree(h->ws); (void)hipFree(h->prof); (void)hipFree(h->ord_chk); (void)hipFree(h->it_buf); free(h); return NMPC_E_NOMEM; }
     h->P.trace_inst = opts ? opts->trace_instance : -1;
     *out = h;
     return NMPC_OK;
@@ -172,6 +174,7 @@ int32_t nmpc_destroy(nmpc_handle_t *h)
     if (h->prof) (void)hipFree(h->prof);
     if (h->ord_chk) (void)hipFree(h->ord_chk);
     if (h->it_buf) (void)hipFree(h->it_buf);
+    if (h->st_buf) (void)hipFree(h->st_buf);
     free(h);
     return NMPC_OK;
 }
@@ -254,13 +257,16 @@ int32_t nmpc_step_batch(nmpc_handle_t *h, int32_t B, double *p, double *w, doubl
     if (B == 0) return NMPC_OK;
     if (!p || !w || !w_sol || w == w_sol) return NMPC_E_ARG;
     int32_t *it = iters ? iters : h->it_buf;
+    int32_t *stt = status ? status : h->st_buf;
     // 1. the solve, dispatched in the caller's order (checked to be a permutation; ignored otherwise)
-    int32_t rc = solve_impl(h, B, p, w, w_sol, obj, status, it, kkt, order, stream);
+    int32_t rc = solve_impl(h, B, p, w, w_sol, obj, stt, it, kkt, order, stream);
     if (rc != NMPC_OK) return rc;
     DeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    // 2. guess <- shift(solution) in place of the old guess; x0 <- x0 + T f(x0, u_0) in place of the x0 half of p
-    if (nmpc::launch_shift(h->P, h->cfg.m, B, p, w_sol, w, p, 2 * 3 * h->cfg.m, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
+    // 2. guess <- shift(solution) in place of the old guess; x0 <- x0 + T f(x0, u_0) in place of the x0 half of p.  An instance whose solve
+    //    ended with status 2 (numerical failure: the iterate may be non-finite) or 3 (infeasible x0) keeps its guess and its x0;
+    //    status 1 / 4 return a finite last iterate and are shifted like a converged one, as the scripts do with any IPOPT return
+    if (nmpc::launch_shift(h->P, h->cfg.m, B, p, w_sol, w, p, 2 * 3 * h->cfg.m, stt, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
     // 3. the next period's dispatch order: longest solves of this period first
     if (order && nmpc::launch_order_by_iters(B, it, order, (hipStream_t)stream) != hipSuccess) return NMPC_E_HIP;
     return NMPC_OK;
@@ -285,7 +291,7 @@ int32_t nmpc_shift_batch(nmpc_handle_t *h, int32_t B, const double *p_in, const 
     if (x0_next && !p_in) return NMPC_E_ARG;
     DeviceScope dev(h->device);
     if (!dev.ok) return NMPC_E_HIP;
-    hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, 0, (hipStream_t)stream);
+    hipError_t e = nmpc::launch_shift(h->P, h->cfg.m, B, p_in, w_in, w_next, x0_next, 0, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? NMPC_OK : NMPC_E_HIP;
 }
 
@@ -328,14 +334,16 @@ int32_t nmpc_debug_profile(nmpc_handle_t *h, int64_t *out12, int32_t reset)
 }
 int32_t nmpc_debug_trace(nmpc_handle_t *h, double *out, int32_t rows)
 {
-    if (!h || !out || rows > 2048) return NMPC_E_ARG;
+    if (!h || !out || rows < 0 || rows > 2048) return NMPC_E_ARG;
+    if (rows == 0) return NMPC_OK;
     if (hipDeviceSynchronize() != hipSuccess) return NMPC_E_HIP;
     if (hipMemcpy(out, h->prof + 12, (size_t)rows * 16 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
     return NMPC_OK;
 }
 int32_t nmpc_debug_trace2(nmpc_handle_t *h, double *out, int32_t rows)
 {
-    if (!h || !out || rows > 2048) return NMPC_E_ARG;
+    if (!h || !out || rows < 0 || rows > 2048) return NMPC_E_ARG;
+    if (rows == 0) return NMPC_OK;
     if (hipMemcpy(out, h->prof + 12 + 16 * 2048, (size_t)rows * 8 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
     return NMPC_OK;
 }
@@ -347,7 +355,7 @@ int64_t nmpc_debug_workspace(nmpc_handle_t *h, int32_t inst, double *out, int64_
     int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
     if (offs) { offs[0] = h->kernel; offs[1] = h->P.oKG; offs[2] = h->P.oKFF; offs[3] = h->P.oPACK; offs[4] = h->P.oKT; }
     if (!out) return per;
-    if (cap < per) return NMPC_E_ARG;
+    if (cap < per || inst < 0 || inst >= h->max_batch) return NMPC_E_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return NMPC_E_HIP;
     if (hipMemcpy(out, h->ws + (size_t)inst * per, (size_t)per * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NMPC_E_HIP;
     return per;

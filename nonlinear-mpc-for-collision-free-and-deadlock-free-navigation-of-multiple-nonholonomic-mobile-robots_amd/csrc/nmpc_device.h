@@ -40,7 +40,7 @@ hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, con
 size_t col_kernel_bytes(const KParams &P, int m, int shape);
 void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *kt_off, int64_t *stride);
 hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const double *w, double *f, double *g, hipStream_t st);
-hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st);      // x0_stride: doubles between the x0_next rows (0 = n_x)
+hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, const int32_t *keep_status, hipStream_t st);      // x0_stride: doubles between the x0_next rows (0 = n_x); keep_status: instances with status 2 / 3 there are left untouched (or nullptr)
 hipError_t launch_order_by_iters(int B, const int32_t *iters, int32_t *order, hipStream_t st);
 hipError_t launch_odometry(long n, const double *odom, const double *init, double *pose, int wrap, hipStream_t st);
 hipError_t launch_order_check(int B, const int32_t *order, int32_t *count, int32_t *bad, hipStream_t st);

@@ -895,8 +895,10 @@ __global__ __launch_bounds__(256) void eval_kernel(const KParams P, int B, const
 // warm-start shift (C6:160-169,460-465) + optional plant step (casadi_test.py:17-26)
 template <int M_>
 __global__ __launch_bounds__(256) void shift_kernel(const KParams P, int B, const double *p_in, const double *__restrict__ w_in,
-                                                     double *__restrict__ w_next, double *x0_next, int x0_stride)
+                                                     double *__restrict__ w_next, double *x0_next, int x0_stride, const int32_t *__restrict__ keep_status)
 {
+    // keep_status (nmpc_step_batch): an instance whose solve ended with a numerical failure (2) or an infeasible x0 (3) — possibly a non-finite
+    // iterate — keeps its guess and its x0: nothing of it is overwritten, the caller can still apply a fallback
     constexpr int NX = Geo<M_>::NX, NU = Geo<M_>::NU;
     const int N = P.N;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -913,10 +915,12 @@ __global__ __launch_bounds__(256) void shift_kernel(const KParams P, int B, cons
             int eu = e - nX, k = eu / NU, c = eu - k * NU;
             v = (k < N - 1) ? src[nX + (k + 1) * NU + c] : src[nX + (N - 1) * NU + c];
         }
-        w_next[gid] = v;
+        const bool keep = keep_status && (keep_status[b] == NMPC_STATUS_NUMERIC || keep_status[b] == NMPC_STATUS_INFEASIBLE_X0);
+        if (!keep) w_next[gid] = v;
     }
     if (x0_next && gid < (long)B * M_) {
         const int b = (int)(gid / M_), i = (int)(gid - (long)b * M_);
+        if (keep_status && (keep_status[b] == NMPC_STATUS_NUMERIC || keep_status[b] == NMPC_STATUS_INFEASIBLE_X0)) return;
         const double *x0 = p_in + (size_t)b * 2 * NX + 3 * i;
         const double *u = w_in + (size_t)b * P.nvar + (size_t)(N + 1) * NX + 2 * i;
         double s, c;
@@ -945,10 +949,10 @@ template <int M_> static hipError_t launch_eval_m(const KParams &P, int B, const
     hipLaunchKernelGGL((eval_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w, f, g);
     return hipGetLastError();
 }
-template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st)
+template <int M_> static hipError_t launch_shift_m(const KParams &P, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, const int32_t *keep_status, hipStream_t st)
 {
     long total = (long)B * P.nvar;
-    hipLaunchKernelGGL((shift_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w_in, w_next, x0n, x0_stride ? x0_stride : Geo<M_>::NX);
+    hipLaunchKernelGGL((shift_kernel<M_>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, B, p, w_in, w_next, x0n, x0_stride ? x0_stride : Geo<M_>::NX, keep_status);
     return hipGetLastError();
 }
 
@@ -1061,9 +1065,9 @@ hipError_t launch_eval(const KParams &P, int m, int B, const double *p, const do
     NMPC_DISPATCH(m, C_)
 #undef C_
 }
-hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, hipStream_t st)
+hipError_t launch_shift(const KParams &P, int m, int B, const double *p, const double *w_in, double *w_next, double *x0n, int x0_stride, const int32_t *keep_status, hipStream_t st)
 {
-#define C_(M) launch_shift_m<M>(P, B, p, w_in, w_next, x0n, x0_stride, st)
+#define C_(M) launch_shift_m<M>(P, B, p, w_in, w_next, x0n, x0_stride, keep_status, st)
     NMPC_DISPATCH(m, C_)
 #undef C_
 }

@@ -1006,7 +1006,10 @@ __global__ __launch_bounds__(256) void lidar_scan_kernel(long B, int R, int K, c
     for (int o = 0; o < K; o++) {
         const double *ob = world + ((size_t)b * K + o) * 3;
         const double fx = ob[0] - x, fy = ob[1] - y, t = fx * c + fy * s, h2 = fx * fx + fy * fy - t * t, r2 = ob[2] * ob[2];
-        if (t > 0.0 && h2 < r2) best = fmin(best, t - sqrt(r2 - h2));
+        // the near intersection of the ray with the circle; a pose inside (or touching) an obstacle reads range 0 on every ray (the
+        // near root is negative there, and a negative range would enter the NLP as a distance state)
+        if (fx * fx + fy * fy <= r2) best = 0.0;
+        else if (t > 0.0 && h2 < r2) best = fmin(best, fmax(t - sqrt(r2 - h2), 0.0));
     }
     scan[gid] = best;
 }
@@ -1058,7 +1061,7 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
     h->cfg = *cfg; h->max_batch = max_batch;
     h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3 + 2 * NMPC_LIDAR_MAX_RAYS + (size_t)N * 12);
-    if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU (N ~ 1000 with Nc = N / 2)
+    if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU: 8 (16 (N + 1) + 16 Nc + 12 N + 32) bytes <= 160 KB, i.e. N <= ~560 with Nc = N / 2
     nmpc_lidar::LParams &P = h->P;
     memset(&P, 0, sizeof(P));
     P.N = N; P.Nc = Nc; P.R = R; P.ns = ns; P.max_iter = cfg->max_iter; P.nvar = nv; P.ng = nmpc_lidar_n_g(cfg); P.np = nmpc_lidar_n_p(cfg);

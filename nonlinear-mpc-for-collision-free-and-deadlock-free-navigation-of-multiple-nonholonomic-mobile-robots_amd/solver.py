@@ -87,8 +87,9 @@ class NmpcSolver:
     def __init__(self, cfg: ProblemConfig, max_batch: int = 1, device: Optional[int] = None, kernel: Optional[int] = None,
                  trace_instance: Optional[int] = None):
         """kernel: None / 0 = the library picks the solve kernel per batch size; 1 / 2 / 3 pins the HBM-resident / element-per-lane /
-        column-per-lane kernel (nmpc_options_t).  The library itself reads no environment variable; this host class does, for
-        development: NMPC_KERNEL and NMPC_TRACE_INST supply the two options when the arguments are not given."""
+        column-per-lane (throughput shape) kernel, 4 / 5 the column kernel's latency shape with two / four wavefronts per instance
+        (nmpc_options_t).  The library itself reads no environment variable; this host class does, for development: NMPC_KERNEL (its
+        first character, '1'..'5'; anything else = 0) and NMPC_TRACE_INST supply the two options when the arguments are not given."""
         import os
         self.cfg = cfg
         self.torch = _torch()
@@ -99,7 +100,7 @@ class NmpcSolver:
         self.max_batch = int(max_batch)
         with self.torch.cuda.device(self.device):
             kv = os.environ.get("NMPC_KERNEL", "")
-            opts = _lib.COptions(kernel=int(kernel) if kernel is not None else (int(kv) if kv[:1] in ("1", "2", "3", "4", "5") else 0),
+            opts = _lib.COptions(kernel=int(kernel) if kernel is not None else (int(kv[:1]) if kv[:1] in ("1", "2", "3", "4", "5") else 0),
                                  trace_instance=int(trace_instance) if trace_instance is not None else int(os.environ.get("NMPC_TRACE_INST", "-1")))
             _lib.check(self.lib.nmpc_create_opts(C.byref(self._ccfg), self.max_batch, C.byref(opts), C.byref(self._h)), "nmpc_create_opts")
         self.n_var, self.n_g, self.n_p = cfg.n_var, cfg.n_g, cfg.n_p
@@ -121,8 +122,8 @@ class NmpcSolver:
 
     def kernel_for_batch(self, B: int, ordered: bool = False) -> int:
         """the solve kernel nmpc_solve_batch launches for a batch of B (ordered: with a dispatch-order hint): 3 / 4 column-per-lane in its
-        throughput / latency shape, 2 element-per-lane, 1 HBM-resident (nmpc_query)"""
-        return int(self.lib.nmpc_query(self._h, 5 if ordered else _lib.QUERY_KERNEL_FOR_BATCH, int(B)))
+        throughput / latency shape (4 covers two and four wavefronts per instance), 2 element-per-lane, 1 HBM-resident (nmpc_query)"""
+        return int(self.lib.nmpc_query(self._h, _lib.QUERY_KERNEL_FOR_ORDERED_BATCH if ordered else _lib.QUERY_KERNEL_FOR_BATCH, int(B)))
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

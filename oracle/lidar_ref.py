@@ -225,6 +225,8 @@ def scan_of_world(pose, obstacles, R, scan_max=3.5):
             fx, fy = ox - x, oy - y
             t = fx * dx + fy * dy
             h2 = fx * fx + fy * fy - t * t
-            if t > 0 and h2 < r * r:
-                out[m] = min(out[m], t - np.sqrt(r * r - h2))
+            if fx * fx + fy * fy <= r * r:      # a pose inside (or touching) an obstacle reads range 0 on every ray
+                out[m] = 0.0
+            elif t > 0 and h2 < r * r:
+                out[m] = min(out[m], max(t - np.sqrt(r * r - h2), 0.0))
     return out

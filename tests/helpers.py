@@ -48,6 +48,20 @@ def to_product_cfg(ocfg, **kw):
                                   rob_dim=ocfg.rob_dim, margin=ocfg.margin, pad_value=ocfg.pad_value, pad_rows=ocfg.pad_rows, **kw)
 
 
+def to_oracle_cfg(pcfg):
+    """product ProblemConfig -> oracle NLPConfig (the checker's own type; bench.make_batch returns the product's)."""
+    return R.NLPConfig(m=pcfg.m, N=pcfg.N, T=pcfg.T, dmin=pcfg.dmin, q=tuple(pcfg.q), r=tuple(pcfg.r), v_max=pcfg.v_max, w_max=pcfg.w_max,
+                       xy_max=pcfg.xy_max, th_max=pcfg.th_max, obstacles=list(pcfg.obstacles), rob_dim=pcfg.rob_dim, margin=pcfg.margin,
+                       pad_value=pcfg.pad_value, pad_rows=pcfg.pad_rows, pair_rows=pcfg.pair_rows)
+
+
+def bench_batch(name, B=0, rank=0, shard=None):
+    """bench.make_batch with the oracle's config type in front: (oracle NLPConfig, B, P, W0)."""
+    import bench
+    pcfg, B, P, W0 = bench.make_batch(name, rank, B, shard=shard)
+    return to_oracle_cfg(pcfg), B, P, W0
+
+
 def closed_loop_oracle(ocfg, x0, goals, max_steps, stop_tol=5e-2, max_iter=2000):
     """The reference's main loop (casadi_test.py:143-183; goal sequencing of centralized_one_robots_implementation.py:176-239)
     driven by the CPU oracle — checker for nmpc_amd.simulate_closed_loop."""

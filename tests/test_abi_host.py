@@ -413,3 +413,27 @@ def test_dpp_reads_of_the_column_kernel_keep_their_wait_states(built, tmp_path):
         n, hz = asm_hazards.check(_col_kernel_asm(tmp_path, m), "_ZN4nmpc16solve_col_kernel")
         print("m=%d: %d DPP multiply-adds, %d hazards" % (m, n, len(hz)))
         assert n >= least and not hz, (m, n, hz[:5])
+
+
+def test_bench_workload_is_built_from_the_product_side():
+    """bench.py builds its workload from nmpc_amd presets and its own generator; oracle/ and tests/ are imported only in
+    the cpu_baseline / casadi legs (inside `if ... args.cpu_sample != 0` blocks).  The literal start/goal sets it carries equal the oracle's."""
+    import importlib.util, re
+    path = os.path.join(ROOT, "bench.py")
+    spec = importlib.util.spec_from_file_location("bench", path)
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert np.array_equal(np.concatenate(bench.C6_LITERAL), np.concatenate([R.C6_START, R.C6_GOAL]))
+    assert np.array_equal(np.concatenate(bench.C2_LITERAL), np.concatenate([R.C2_START, R.C2_GOAL]))
+    src = open(path).read().split("\n")
+    for i, line in enumerate(src):
+        if re.search(r"^\s*(from|import) (oracle|tests)\b", line):
+            # the nearest enclosing `if` at a smaller indent must be a cpu_sample guard
+            ind = len(line) - len(line.lstrip())
+            j = i - 1
+            while j >= 0 and not (src[j].strip().startswith("if ") and len(src[j]) - len(src[j].lstrip()) < ind):
+                j -= 1
+            assert j >= 0 and "cpu_sample != 0" in src[j], (i + 1, line, src[j] if j >= 0 else None)
+    # the product config of every workload equals the oracle's own definition of the same script literals
+    from tests import helpers as Hh
+    for name, oc in (("two", R.cfg_two(20)), ("six", R.cfg_six(20)), ("ten20", R.cfg_ten(20)), ("ten", R.cfg_ten(30))):
+        assert Hh.to_oracle_cfg(bench.workload(name)[0]) == oc, name

@@ -205,6 +205,14 @@ def test_lidar_edge_cases(built):
     one = s.scan_batch(pose[:1], np.array([[ob]]), scan_max=3.5).cpu().numpy()[0]
     ref1 = LR.scan_of_world(pose[0], [ob], cfg.R)
     assert np.abs(one - ref1).max() <= 1e-13 and abs(one[0] - 0.75) <= 1e-12 and (one[1:] == 3.5).all()
+    # a pose inside an obstacle's circle reads range 0 on every ray (never a negative range); a pose touching it reads ~0
+    # on the ray through the contact point; the device scan equals the checker's
+    inside = np.array([[float(ob[0]) - 0.1, float(ob[1]), 0.3]])
+    sin_ = s.scan_batch(inside, np.array([[ob]])).cpu().numpy()[0]
+    assert (sin_ == 0.0).all() and np.array_equal(sin_, LR.scan_of_world(inside[0], [ob], cfg.R))
+    tang = np.array([[float(ob[0]) - (0.25 + 1e-9) * np.cos(0.3), float(ob[1]) - (0.25 + 1e-9) * np.sin(0.3), 0.3]])      # a nanometre off the surface
+    st_ = s.scan_batch(tang, np.array([[ob]])).cpu().numpy()[0]
+    assert (st_ >= 0.0).all() and st_[0] <= 1e-7 and np.abs(st_ - LR.scan_of_world(tang[0], [ob], cfg.R)).max() <= 1e-7
     assert L.nmpc_lidar_scan_batch(1, cfg.R, 1, None, None, C.c_double(3.5), None, None) == -1
     assert L.nmpc_lidar_scan_batch(0, cfg.R, 0, None, None, C.c_double(3.5), None, None) == 0
     assert L.nmpc_lidar_scan_batch(1, 99, 0, None, None, C.c_double(3.5), None, None) == -1

@@ -251,7 +251,7 @@ def test_full_size_bench_batches_match_oracle(built, name, B):
     import torch
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    ocfg, _, P, W0 = bench.make_batch(name, 0, B)
+    ocfg, _, P, W0 = Hh.bench_batch(name, B)
     r = _np(_solver(ocfg, B, max_iter=2000).solve_batch(P, W0)); torch.cuda.synchronize()
     ref = O.solve_batch(O.make_config(ocfg, max_iter=2000), P, W0)
     assert (r["status"] == ref["status"]).all() and (r["status"] == 0).all()
@@ -304,6 +304,35 @@ def test_step_batch_equals_the_separate_calls(built):
     assert L.nmpc_step_batch(s._h, B, p1.data_ptr(), w1.data_ptr(), xs_.data_ptr(), None, None, None, None, None, None) == 0
     assert L.nmpc_step_batch(s._h, B, p1.data_ptr(), w1.data_ptr(), w1.data_ptr(), None, None, None, None, None, None) == -1      # w_sol aliases w
     torch.cuda.synchronize()
+
+
+def test_step_batch_leaves_failed_instances_untouched(built):
+    """ADVICE r3 / include/nmpc.h: nmpc_step_batch updates p[:, :n_x] and w in place — except for an instance whose solve ends with status 2
+    (numerical failure) or 3 (infeasible x0): its x0 and its guess stay as they were, so the caller can still fall back; a solve cut off by
+    max_iter (status 1) returns a finite iterate and is shifted like a converged one (the scripts apply whatever IPOPT returns).  Forced
+    here with an x0 that violates a pair row (status 3) and with max_iter = 1 (status 1), also with status == NULL at the C ABI."""
+    import torch
+    ocfg = R.cfg_two(20)
+    B = 6
+    P, W0 = Hh.batch(ocfg, B, 1)
+    P[2, 3:5] = P[2, 0:2] + 0.01                      # robot 1 on top of robot 0: the stage-0 pair row fails the pre-check (status 3)
+    W0[2] = R.cold_start(ocfg, P[2, : ocfg.nx])
+    s1 = _solver(ocfg, B, max_iter=1)
+    p = torch.as_tensor(P, device="cuda").clone(); w = torch.as_tensor(W0, device="cuda").clone()
+    r = s1.step_batch(p, w, None)
+    torch.cuda.synchronize()
+    st = r["status"].cpu().numpy()
+    assert st[2] == 3 and (np.delete(st, 2) == 1).all(), st
+    pn, wn = p.cpu().numpy(), w.cpu().numpy()
+    assert np.array_equal(pn[2], P[2]) and np.array_equal(wn[2], W0[2])                       # the failed instance: nothing overwritten
+    wshift, x0n = O.shift_batch(O.make_config(ocfg), P, r["x"].cpu().numpy())
+    keep = np.arange(B) != 2
+    assert np.array_equal(wn[keep], wshift[keep]) and np.abs(pn[keep, : ocfg.nx] - x0n[keep]).max() <= 1e-14 and np.array_equal(pn[:, ocfg.nx:], P[:, ocfg.nx:])
+    # the same through the raw ABI with status == NULL (the library keeps the statuses in its own buffer)
+    p2 = torch.as_tensor(P, device="cuda").clone(); w2 = torch.as_tensor(W0, device="cuda").clone(); ws2 = torch.empty_like(w2)
+    assert s1.lib.nmpc_step_batch(s1._h, B, p2.data_ptr(), w2.data_ptr(), ws2.data_ptr(), None, None, None, None, None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p) and torch.equal(w2, w)
 
 
 def test_kernel_selection_by_team_size_and_batch(built):

@@ -155,9 +155,9 @@ def test_stall_case_and_composite_failures_are_rescued_by_the_cold_start_retry()
     # without the retry the stall case fails (what the fixture was captured for), and with one retry only the cases2 do
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import numpy as np, sys; sys.path.insert(0, %r); import bench; from oracle import nlp_ref as R, oracle_lib as O; "
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from tests import helpers as Hh; from oracle import nlp_ref as R, oracle_lib as O; "
             "d = np.load(%r); p = d['p'] if d['p'].ndim == 2 else d['p'][None]; w = d['w'] if d['w'].ndim == 2 else d['w'][None]; "
-            "r = O.solve_batch(O.make_config(bench._composite(R), max_iter=2000), p, w); print('STATUS', r['status'].tolist())")
+            "r = O.solve_batch(O.make_config(Hh.bench_batch('composite', 1)[0], max_iter=2000), p, w); print('STATUS', r['status'].tolist())")
     out = subprocess.run([sys.executable, "-c", code % (root, os.path.join(gold, "stall_case.npz"))], capture_output=True, text=True,
                          env=dict(os.environ, NMPC_ORACLE_NO_COLD_RETRY="1"), timeout=300)
     assert "STATUS [4]" in out.stdout, (out.stdout, out.stderr[-500:])

@@ -23,7 +23,8 @@ sys.path.insert(0, %r)
 import bench
 from oracle import oracle_lib as O
 name, n, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-ocfg, B, P, W0 = bench.make_batch(name, 0, n)
+from tests import helpers as Hh
+ocfg, B, P, W0 = Hh.bench_batch(name, n)
 r = O.solve_batch(O.make_config(ocfg), P, W0)
 np.savez(out, x=r["x"], f=r["f"], status=r["status"], iters=r["iters"], kkt=r["kkt"])
 ''' % ROOT

@@ -8,7 +8,8 @@ import nmpc_amd, bench
 from tests import helpers as Hh
 name = sys.argv[1] if len(sys.argv) > 1 else "six"
 sizes = [int(a) for a in sys.argv[2:]] or [1, 64, 512, 1024, 2048, 4096]
-ocfg, _, P, W0 = bench.make_batch(name, 0, max(sizes))
+from tests import helpers as Hh
+ocfg, _, P, W0 = Hh.bench_batch(name, max(sizes))
 cfg = Hh.to_product_cfg(ocfg)
 s3 = nmpc_amd.NmpcSolver(cfg, max_batch=max(sizes), kernel=3)
 s4 = nmpc_amd.NmpcSolver(cfg, max_batch=max(sizes), kernel=int(os.environ.get("LAT_KERNEL", "4")))      # LAT_KERNEL=5: four wavefronts per instance (five / six robots)

@@ -8,9 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 def child(name, i0, i1):
-    import bench
+    from tests import helpers as Hh
     from oracle import oracle_lib as O
-    ocfg, B, P, W0 = bench.make_batch(name, 0, i1)
+    ocfg, B, P, W0 = Hh.bench_batch(name, i1)
     oc = O.make_config(ocfg)
     for b in range(i0, i1):
         sys.stderr.write("INST %d\n" % b); sys.stderr.flush()

@@ -5,13 +5,13 @@ import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench
+from tests import helpers as Hh
 from oracle import oracle_lib as O
 L = O.lib(); L.nmpc_oracle_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for name in (sys.argv[3:] or ["six", "composite", "ten20", "two"]):
-    ocfg, _, P, W = bench.make_batch(name, 0, B)
+    ocfg, _, P, W = Hh.bench_batch(name, B)
     oc = O.make_config(ocfg, max_iter=2000)
     st4 = (C.c_double * 4)(); L.nmpc_oracle_stats(st4, 1)
     its = []; fails = 0; t = time.time()

@@ -21,14 +21,14 @@ sys.path.insert(0, ROOT)
 
 
 def child(B, names):
-    import bench
+    from tests import helpers as Hh
     from oracle import oracle_lib as O
     L = O.lib()
     L.nmpc_oracle_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
     out = {}
     for name in names:
         nb = {"six": B, "two": B, "ten20": max(64, B // 4), "ten": max(64, B // 4), "composite": max(64, B // 2)}[name]
-        ocfg, _, P, W0 = bench.make_batch(name, 0, nb)
+        ocfg, _, P, W0 = Hh.bench_batch(name, nb)
         st4 = (C.c_double * 4)()
         L.nmpc_oracle_stats(st4, 1)
         t = time.time(); r = O.solve_batch(O.make_config(ocfg, max_iter=2000), P, W0); dt = time.time() - t

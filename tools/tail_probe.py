@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nmpc_amd, bench
 from tests import helpers as Hh
-ocfg, B, P, W0 = bench.make_batch("six", 0)
+from tests import helpers as Hh
+ocfg, B, P, W0 = Hh.bench_batch("six")
 cfg = Hh.to_product_cfg(ocfg)
 os.environ["NMPC_KERNEL"] = os.environ.get("TAIL_KERNEL", "3")
 s = nmpc_amd.NmpcSolver(cfg, max_batch=B)

@@ -22,7 +22,8 @@ from oracle import oracle_lib as O
 
 name = sys.argv[1] if len(sys.argv) > 1 else "six"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-ocfg, B, P, W0 = bench.make_batch(name, 0, B)
+from tests import helpers as Hh
+ocfg, B, P, W0 = Hh.bench_batch(name, B)
 it = O.solve_batch(O.make_config(ocfg, max_iter=2000), P, W0)["iters"].astype(int)
 print("%s B=%d: mean %.1f, max %d iterations; longest: %s" % (name, B, it.mean(), it.max(), np.argsort(-it)[:6]))
 LONE, LOADED, LAT_LONE, LAT_LOADED = 130e-6, 184e-6, 104e-6, 150e-6
