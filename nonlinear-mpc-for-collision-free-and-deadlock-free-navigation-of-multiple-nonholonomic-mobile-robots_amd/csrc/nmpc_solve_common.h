@@ -91,12 +91,20 @@ template <int TPB> __device__ __forceinline__ void lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// reciprocal: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, a third of the cost of an IEEE division chain)
+// reciprocal of a pivot: v_rcp_f64 seed + Newton steps.  NMPC_RCP_STEPS = 1 (round 4): the seed is good to about single precision, one step
+// leaves ~1e-14 relative — the factorisation of an interior-point step does not need more (iteration counts of the bench batches equal to
+// 1e-5 relative, parity tests unchanged) and the two dependent multiply-adds it saves sit on the pivot chain of every stage: A/B in one
+// session, six robots B=4096 +2.3 %, B=16384 +1.2 %.  2 = full fp64 accuracy (rounds 2-3).
+#ifndef NMPC_RCP_STEPS
+#define NMPC_RCP_STEPS 1
+#endif
 __device__ __forceinline__ double rcp_nr(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
+#if NMPC_RCP_STEPS >= 2
     r = fma(fma(-d, r, 1.0), r, r);
+#endif
     return r;
 }
 

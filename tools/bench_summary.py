@@ -1,8 +1,17 @@
-"""Development aid: one line per workload of a bench.py JSON line (stdin or file)."""
+"""Development aid: one line per workload of a bench.py JSON line.   python tools/bench_summary.py [bench.json]"""
 import json, sys
-d = json.load(open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin)
-print("six", round(d["value"]), "closed-loop", round(d["closed_loop"]["solves_per_s"]), "host-buffers", round(d["host_buffers"]["solves_per_s"]),
-      "same-basin vs cpu", d["cpu_baseline"].get("same_basin_frac_vs_gpu"), "conv", d["solve_stats"]["converged_frac"], "iters", round(d["solve_stats"]["mean_iters"], 2))
+d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/bench.json"))
+rl = d["roofline"]; ss = d["solve_stats"]
+print("%-46s %9.0f solves/s %7.2f ms  iters %.2f / %d  frac %.4f (sustained %.4f)  traffic %s" % (
+    d["config"]["workload"][:46], d["value"], d["ms_per_step"], ss["mean_iters"], ss["max_iters"], rl["frac"], rl.get("frac_sustained", 0.0),
+    ("%.0f GB/s" % rl["traffic_GBps"]) if rl.get("traffic") else "null"))
+for k in ("closed_loop", "host_buffers"):
+    if k in d:
+        print("%-46s %9.0f solves/s %7.2f ms" % (k, d[k]["solves_per_s"], d[k]["ms_per_step"]))
 for s in d.get("sweep", []):
-    print("  ", s["workload"][:40], round(s["value"]), "iters", round(s["mean_iters"], 2), "conv", s["converged_frac"])
-print(d["library"])
+    r = s["roofline"]
+    print("%-46s %9.0f solves/s %7.2f ms  iters %.2f / %d  frac %.4f  traffic %s  %s" % (
+        s["workload"][:46], s["value"], s["ms_per_step"], s["mean_iters"], s["max_iters"], r["frac"], ("%.0f GB/s" % r["traffic_GBps"]) if r.get("traffic") else "null", s["status_counts"]))
+for k in ("cpu_baseline", "casadi"):
+    if k in d:
+        print(k, d[k] if isinstance(d[k], str) else {a: d[k][a] for a in ("value", "cores", "kind") if a in d[k]})
