@@ -59,7 +59,7 @@ extern "C" {
  * AS/third_scenario_mpc_obstacle_avoidance.py:58,97-119,175-177).
  */
 typedef struct nmpc_config {
-    int32_t m;              /* robots: 1..6, 8 or 10 (the team sizes of the reference scripts); 7 and 9 -> NMPC_E_UNSUPPORTED */
+    int32_t m;              /* robots: 1..10 (the reference scripts use 1..6, 8 and 10; 7 and 9 are instantiated since round 4); beyond -> NMPC_E_UNSUPPORTED */
     int32_t N;              /* horizon, 2..4096                                                 */
     int32_t n_obs;          /* static circular obstacles, 0..NMPC_MAX_OBSTACLES                 */
     int32_t pad_rows;       /* 1: initial g block carries M constant rows (C6:278); 0: it does not */

@@ -41,7 +41,7 @@ struct DeviceScope {
     ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 
-static bool m_supported(int m) { return (m >= 1 && m <= 6) || m == 8 || m == 10; }
+static bool m_supported(int m) { return m >= 1 && m <= NMPC_MAX_ROBOTS; }      // every team size 1..10 is instantiated (7 and 9 since round 4)
 
 extern "C" {
 

@@ -1047,7 +1047,9 @@ hipError_t launch_order_by_iters(int B, const int32_t *iters, int32_t *order, hi
     case 4: return CALL(4);                                                                                                       \
     case 5: return CALL(5);                                                                                                       \
     case 6: return CALL(6);                                                                                                       \
+    case 7: return CALL(7);                                                                                                       \
     case 8: return CALL(8);                                                                                                       \
+    case 9: return CALL(9);                                                                                                       \
     case 10: return CALL(10);                                                                                                     \
     default: return hipErrorInvalidValue;                                                                                         \
     }

@@ -1536,7 +1536,9 @@ hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, con
     case 4: return launch3_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
     case 5: return launch3_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
     case 6: return launch3_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 7: return launch3_m<7>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
     case 8: return launch3_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 9: return launch3_m<9>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
     case 10: return launch3_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 #else
     case NMPC_COL_ONLY_M: return launch3_m<NMPC_COL_ONLY_M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
@@ -1550,7 +1552,7 @@ size_t col_kernel_bytes(const KParams &P, int m, int shape)
 {
 #define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 1>(P)) : col_lds_bytes<M, 0>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 0>(P));
     switch (m) {
-        LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(8) LB(10)
+        LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(7) LB(8) LB(9) LB(10)
     default: return 0;
     }
 #undef LB

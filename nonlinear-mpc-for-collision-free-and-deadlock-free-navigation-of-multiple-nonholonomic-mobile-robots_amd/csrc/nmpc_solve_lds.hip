@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     const bool gact = tid < HG * NZ;
     const int gx0 = term_ix(gcol, 0), gx1 = term_ix(gcol, 1), gx2 = term_ix(gcol, 2);
     constexpr int GRPT = (NX + HG - 1) / HG;                                   // rows per thread in the G pass
-    constexpr int PBP = (64 / NX >= 3) ? 3 : (64 / NX >= 2 ? 2 : 1), PBC = (NX + PBP - 1) / PBP;   // parts / columns per part of the P b product
+    constexpr int PBP = (64 / NX >= 3 && NX % 3 == 0) ? 3 : ((64 / NX >= 2 && NX % 2 == 0) ? 2 : 1), PBC = (NX + PBP - 1) / PBP;   // parts / columns per part of the P b product (exact splits only: nine robots, NX = 27, take one part)
     static_assert(PBP * PBC == NX, "P b split must be exact");
     const int gpb0 = oPf + 8 * (grow0 * NX + gx0), gpb1 = oPf + 8 * (grow0 * NX + gx1), gpb2 = oPf + 8 * (grow0 * NX + gx2);
     const int gwb = oGb + 8 * (grow0 * G::LDG + gcol);
@@ -1132,7 +1132,9 @@ hipError_t launch_solve_lds(const KParams &P, int m, int B, const double *p, con
     case 4: return launch2_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     case 5: return launch2_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     case 6: return launch2_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 7: return launch2_m<7>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     case 8: return launch2_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
+    case 9: return launch2_m<9>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     case 10: return launch2_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st);
     default: return hipErrorInvalidValue;
     }
@@ -1144,7 +1146,7 @@ size_t lds_kernel_bytes(const KParams &P, int m)
 {
 #define LB(M, T) case M: return P.thb ? lds_bytes<M, 1>(P, T) : lds_bytes<M, 0>(P, T);
     switch (m) {
-        LB(1, 64) LB(2, 64) LB(3, 64) LB(4, 64) LB(5, 64) LB(6, 64) LB(8, 128) LB(10, 256)
+        LB(1, 64) LB(2, 64) LB(3, 64) LB(4, 64) LB(5, 64) LB(6, 64) LB(7, 128) LB(8, 128) LB(9, 256) LB(10, 256)
     default: return 0;
     }
 #undef LB
@@ -1160,7 +1162,7 @@ void lds_kernel_workspace(const KParams &P, int m, int64_t *pack_off, int64_t *k
         pack = thb ? G2<M, 1>::PACK : G2<M, 0>::PACK;                                                                             \
         kts = thb ? G2<M, 1>::KTS : G2<M, 0>::KTS;                                                                                \
         break;
-    switch (m) { SZ(1) SZ(2) SZ(3) SZ(4) SZ(5) SZ(6) SZ(8) SZ(10) default: break; }
+    switch (m) { SZ(1) SZ(2) SZ(3) SZ(4) SZ(5) SZ(6) SZ(7) SZ(8) SZ(9) SZ(10) default: break; }
 #undef SZ
     int64_t o = 0;
     *pack_off = o; o += (int64_t)(P.N + 1) * pack; o = (o + 15) / 16 * 16;

@@ -94,7 +94,7 @@ def test_create_fails_loudly_without_gpu(built):
     cc = nmpc_amd.centralized_two_robots(20).to_c()
     h = C.c_void_p()
     assert L.nmpc_create(C.byref(cc), 4, C.byref(h)) == -3          # NMPC_E_HIP
-    bad = nmpc_amd.centralized_two_robots(20); bad.m = 7
+    bad = nmpc_amd.centralized_two_robots(20); bad.m = 11
     assert L.nmpc_create(C.byref(bad.to_c()), 4, C.byref(h)) in (-2, -3)
     with pytest.raises(RuntimeError):
         nmpc_amd.nlpsol("solver", "ipopt", nmpc_amd.centralized_two_robots(20), {})

@@ -174,6 +174,8 @@ def _composite_cfg(N=25, seed=7):
     ("three", R.NLPConfig(m=3, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5), 32, 5),
     ("five", R.NLPConfig(m=5, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5), 32, 5),
     ("eight", R.NLPConfig(m=8, N=20, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84), 16, 5),
+    ("seven", R.NLPConfig(m=7, N=20, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84), 16, 5),      # no reference script: the generic solver covers every team size 1..10 (round 4)
+    ("nine", R.NLPConfig(m=9, N=20, T=0.1, dmin=0.3, v_max=0.22, w_max=2.84), 16, 5),
 ])
 @pytest.mark.parametrize("kernel", [None, "3", "4", "5"])
 def test_file_horizons_other_team_sizes_and_composite(built, name, ocfg, B, idx, kernel):

@@ -182,7 +182,7 @@ def test_bad_dispatch_order_hint_is_harmless(built):
 
 
 def test_create_rejects_bad_configs(built):
-    """non-positive R, negative Q / dmin, padding rows without pair rows -> NMPC_E_ARG; m = 7, 9 -> NMPC_E_UNSUPPORTED."""
+    """non-positive R, negative Q / dmin, padding rows without pair rows -> NMPC_E_ARG; m outside 1..10 -> NMPC_E_UNSUPPORTED / NMPC_E_ARG."""
     import ctypes as C
     import nmpc_amd
     L = nmpc_amd._lib.load()
@@ -195,7 +195,7 @@ def test_create_rejects_bad_configs(built):
         return L.nmpc_create(C.byref(c.to_c()), 2, C.byref(h))
     assert rc(r=(0.0, 0.05)) == -1 and rc(r=(0.5, -1.0)) == -1 and rc(q=(1.0, -5.0, 0.1)) == -1 and rc(dmin=-0.1) == -1
     assert rc(pair_rows=False, pad_rows=True) == -1
-    assert rc(m=7) == -2 and rc(m=9) == -2
+    assert rc(m=11) == -2 and rc(m=0) in (-1, -2)      # team sizes 1..10 are all instantiated (7 and 9 since round 4)
     assert L.nmpc_n_var(None) == -1 and L.nmpc_n_g(None) == -1 and L.nmpc_n_p(None) == -1
     assert rc() == 0
     assert L.nmpc_destroy(h) == 0

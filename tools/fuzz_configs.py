@@ -10,7 +10,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1; ncfg = int(sys.argv[2]) if 
 rng = np.random.Generator(np.random.PCG64(seed))
 bad = 0
 for t in range(ncfg):
-    m = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10]))
+    m = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
     N = int(rng.integers(2, 41)) if m <= 6 else int(rng.integers(2, 25))
     K = int(rng.integers(0, 9)) if m <= 3 else int(rng.integers(0, 3))
     cfg = R.NLPConfig(m=m, N=N, T=float(rng.uniform(0.05, 0.3)), dmin=float(rng.uniform(0.15, 0.4)),
