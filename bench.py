@@ -22,8 +22,8 @@ Prints ONE JSON line on rank 0 including
                  SURVEY.md §8(d): iters * (F_kkt + F_asm) per solve, duration from HIP events on the launch stream;
   cpu_baseline — the C oracle (oracle/nmpc_oracle.c, OpenMP, one instance per thread) timed on this box's host cores on a
                  bounded sample of the same workload ("port");
-  sweep        — (N = 1 only) the other north-star shapes, each with its own roofline: m=2 and m=10 at N=20, B=4096; m=10 at
-                 N=30, B=512 (one GPU's shard of BASELINE configs[3]) and B=4096 (the whole batch on one GPU); the six-robot +
+  sweep        — (N = 1 only) the other north-star shapes, each with its own roofline: m=2 (B=4096 and BASELINE configs[1]'s own 1024) and
+                 m=10 at N=20, B=4096; m=10 at N=30, B=512 (one GPU's shard of BASELINE configs[3]) and B=4096 (the whole batch on one GPU); the six-robot +
                  eight-obstacle composite; six robots at B=16384 (the launch outgrows its longest solve); the LIDAR-state NLP with
                  its own flop roofline and CPU baseline.
 """
@@ -368,7 +368,7 @@ def main():
         out["sweep"] = []
         # (workload, batch; 0 = the workload's own): the four north-star shapes, then ten robots at N=30 with the whole BASELINE batch on one
         # GPU (what strong sharding to 512 per GPU is compared with) and six robots at B=16384, where the launch outgrows its longest solve
-        for name, bsz in (("two", 0), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):
+        for name, bsz in (("two", 0), ("two", 1024), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):      # ("two", 1024): BASELINE configs[1]'s own batch
             c2, B2, P2, W2 = make_batch(name, 0, bsz, max_iter=args.max_iter)
             s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
             d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 }
                 for (int o = 0; o < K; o++) {
                     double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), z = ZO[kk * MK + i * K + o];
-                    j0 += dx / rr * z; j1 += dy / rr * z;
+                    j0 += qdiv(dx, rr) * z; j1 += qdiv(dy, rr) * z;
                 }
             }
 #ifdef NMPC_PROFILE
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 }
                 const int sb = k * NXB + (2 + THB) * i;
                 {   // bounds: v = mu/s - sigma (h - s), sigma = z/s, lower row gradient +1, upper row -1
-                    auto bv = [&](double sv, double zv, double hv, double &hd) { double sg = zv / sv; hd += sg; return mu / sv - sg * (hv - sv); };
+                    auto bv = [&](double sv, double zv, double hv, double &hd) { double sg = qdiv(zv, sv); hd += sg; return qdiv(mu, sv) - sg * (hv - sv); };
                     g0 -= bv(x[3 * i] + P.xymax, ZXL[sb], x[3 * i] + P.xymax, h0) - bv(P.xymax - x[3 * i], ZXU[sb], P.xymax - x[3 * i], h0);
                     g1 -= bv(x[3 * i + 1] + P.xymax, ZXL[sb + 1], x[3 * i + 1] + P.xymax, h1) - bv(P.xymax - x[3 * i + 1], ZXU[sb + 1], P.xymax - x[3 * i + 1], h1);
                     if (THB) g2 -= bv(x[3 * i + 2] + P.thmax, ZXL[sb + 2], x[3 * i + 2] + P.thmax, h2) - bv(P.thmax - x[3 * i + 2], ZXU[sb + 2], P.thmax - x[3 * i + 2], h2);
@@ -569,16 +569,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                             constexpr int p = decltype(pc)::value;
                             const int j = p + (p >= i ? 1 : 0);
                             double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
-                            double sv = sq[p], zv = zq[p], sg = zv / sv;
-                            double v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv);
+                            double sv = sq[p], zv = zq[p], sg = qdiv(zv, sv);
+                            double v = qdiv(mu, sv) - sg * (h_pair(dx, dy, P.dmin2) - sv);
                             g0 -= 2 * dx * v; g1 -= 2 * dy * v;
                             h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
                         });
                     }
                     for (int o = 0; o < K; o++) {
-                        double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = dx / rr, n1 = dy / rr;
-                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg = zv / sv, zz = zv / rr;
-                        double v = mu / sv - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv);
+                        double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = qdiv(dx, rr), n1 = qdiv(dy, rr);
+                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg = qdiv(zv, sv), zz = qdiv(zv, rr);
+                        double v = qdiv(mu, sv) - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv);
                         g0 -= n0 * v; g1 -= n1 * v;
                         h0 += sg * n0 * n0 - zz * (1 - n0 * n0); hxy += sg * n0 * n1 + zz * n0 * n1; h1 += sg * n1 * n1 - zz * (1 - n1 * n1);
                     }
@@ -595,9 +595,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                 for (int d = 0; d < 2; d++) {
                     const int eu = k * NU + 2 * i + d;
                     double lo = d ? -P.wmax : -P.vmax, sl = SUL[eu], su = SUU[eu], zl = ZUL[eu], zu = ZUU[eu];
-                    double vl = mu / sl - zl / sl * ((u[d] - lo) - sl), vu = mu / su - zu / su * ((-lo - u[d]) - su);
+                    double vl = qdiv(mu, sl) - qdiv(zl, sl) * ((u[d] - lo) - sl), vu = qdiv(mu, su) - qdiv(zu, su) * ((-lo - u[d]) - su);
                     pk[G::PK_G + 2 * i + d] = 2 * P.r[d] * u[d] - (vl - vu);
-                    pk[G::PK_HD + 2 * i + d] = 2 * P.r[d] + zl / sl + zu / su;
+                    pk[G::PK_HD + 2 * i + d] = 2 * P.r[d] + qdiv(zl, sl) + qdiv(zu, su);
                 }
                 {   // coefficients of [B A] belonging to robot i that depend on the iterate: (v_i: x, y) = T cos, T sin; (theta_i: x, y) = -T v sin, T v cos
                     double *cf = pk + G::PK_CF + 4 * i;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-            double zz = ZPp[k * NP + q], sg = zz / SPp[k * NP + q];
+            double zz = ZPp[k * NP + q], sg = qdiv(zz, SPp[k * NP + q]);
             double *pk = gpack + (size_t)k * G::PACK + G::PK_E + 3 * q;
             pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
         }
@@ -1195,10 +1195,10 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 #endif
         auto fb = [&](double sv, double zv, double ds) -> double {
             double dz = dz_of(mu, sv, zv, ds);
-            if (ds < 0.0) a_p = fmin(a_p, -tau * sv / ds);
-            if (dz < 0.0) a_d = fmin(a_d, -tau * zv / dz);
+            if (ds < 0.0) a_p = fmin(a_p, qdiv(-tau * sv, ds));
+            if (dz < 0.0) a_d = fmin(a_d, qdiv(-tau * zv, dz));
 #if NMPC_FUSE_DPHI
-            dphi_b += ds / sv;
+            dphi_b += qdiv(ds, sv);
 #endif
             return zv + dz;
         };
@@ -1264,11 +1264,11 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                     });
                 }
                 for (int o = 0; o < K; o++) {
-                    double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = ex / rr, n1 = ey / rr;
+                    double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = qdiv(ex, rr), n1 = qdiv(ey, rr);
                     double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o];
                     double nd = n0 * dx[3 * i] + n1 * dx[3 * i + 1];
                     double ds = ds_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
-                    double znew = zv + dz_of(mu, sv, zv, ds), zz = zv / rr;
+                    double znew = zv + dz_of(mu, sv, zv, ds), zz = qdiv(zv, rr);
                     l0 += n0 * znew + zz * (dx[3 * i] - n0 * nd);
                     l1 += n1 * znew + zz * (dx[3 * i + 1] - n1 * nd);
                 }
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double dz = dz_of(mu, sv, zv, ds);
             snew = sv + alpha * ds;
             double z = zv + a_d * dz;
-            return fmin(fmax(z, mu / (1e10 * snew)), 1e10 * mu / snew);
+            return fmin(fmax(z, qdiv(1e-10 * mu, snew)), qdiv(1e10 * mu, snew));
         };
         for (int e = tid; e < N * NU; e += TPB) {
             int c = e % NU;
