@@ -77,6 +77,21 @@ __device__ __forceinline__ double rcp_nr(double d)
     return r;
 }
 
+// Divisions of the stage-parallel phases: v_rcp_f64 + one Newton step and a multiply instead of the IEEE division chain (round 4; as qdiv of
+// nmpc_solve_common.h: <= 2.3e-15 relative, tools/rcp_probe.hip).  NMPC_LIDAR_FAST_DIV=0 restores the divisions (A/B).
+#ifndef NMPC_LIDAR_FAST_DIV
+#define NMPC_LIDAR_FAST_DIV 1
+#endif
+__device__ __forceinline__ double qdiv(double a, double b)
+{
+#if NMPC_LIDAR_FAST_DIV
+    double r = __builtin_amdgcn_rcp(b);
+    return a * fma(fma(-b, r, 1.0), r, r);
+#else
+    return a / b;
+#endif
+}
+
 #ifndef NMPC_LIDAR_DPP
 #define NMPC_LIDAR_DPP 1        // 1: column-per-lane Riccati stage (DPP broadcasts); 0: every lane walks the upper triangle (A/B)
 #endif
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
 #pragma unroll
             for (int m = 0; m < RM; m++)
                 if (M_ON(m)) {
-                    if (lw != 0.0) { double d = dk[m]; f += lw / (d * d); }
+                    if (lw != 0.0) { double d = dk[m]; f += qdiv(lw, d * d); }
                     double sx, sy, e = dn[m] - gdist(m, xn, yn, sx, sy);
                     t_ += fabs(e); e_ = fmax(e_, fabs(e));
                 }
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                                 if (m0 + u < RM && M_ON(m0 + u)) {
                                     double sx, sy; gdist(m0 + u, x, y, sx, sy);
                                     r0 -= et[u] * sx; r1 -= et[u] * sy;
-                                    double rd = et[u] + ((k < N && lw != 0.0) ? -2.0 * lw / (d[u] * d[u] * d[u]) : 0.0);
+                                    double rd = et[u] + ((k < N && lw != 0.0) ? qdiv(-2.0 * lw, d[u] * d[u] * d[u]) : 0.0);
                                     rd -= zl[u] - zu[u];
                                     e_d = fmax(e_d, fabs(rd)); lsum += fabs(et[u]);
                                     comp(d[u], lo[u], hi[u], sl[u], zl[u], su[u], zu[u]);
@@ -394,8 +409,8 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                     // Hessian / gradient contribution of the bound slots of one variable
                     auto slots = [&](double v, double lo, double hi, double sl, double zl, double su, double zu, double &hs, double &gs) {
                         hs = 0.0; gs = 0.0;
-                        if (isfinite(lo)) { const double sg = zl / sl; hs += sg; gs -= mu / sl - sg * ((v - lo) - sl); }
-                        if (isfinite(hi)) { const double sg = zu / su; hs += sg; gs += mu / su - sg * ((hi - v) - su); }
+                        if (isfinite(lo)) { const double sg = qdiv(zl, sl); hs += sg; gs -= qdiv(mu, sl) - sg * ((v - lo) - sl); }
+                        if (isfinite(hi)) { const double sg = qdiv(zu, su); hs += sg; gs += qdiv(mu, su) - sg * ((hi - v) - su); }
                     };
                     {
                         const double pv[3] = {x, y, t};
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                                     double hs, gs;
                                     slots(v, lo[u], hi[u], sl[u], zl[u], su[u], zu[u], hs, gs);
                                     const bool cost = k < N && lw != 0.0;
-                                    const double Wd = hs + (cost ? 6.0 * lw / (v * v * v * v) : 0.0), gd = gs + (cost ? -2.0 * lw / (v * v * v) : 0.0);
+                                    const double Wd = hs + (cost ? qdiv(6.0 * lw, v * v * v * v) : 0.0), gd = gs + (cost ? qdiv(-2.0 * lw, v * v * v) : 0.0);
                                     RV(oWd, k, m) = Wd; RV(ogdv, k, m) = gd;
                                     double sx, sy;
                                     const double re = gdist(m, x, y, sx, sy) - v, tq = gd + Wd * re;      // linearised row: dd = G dx + re
@@ -444,9 +459,9 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             for (int o = lane; o < 2 * Nc; o += 64) {
                 const int j = o >> 1, e = o & 1, cnt = (j < Nc - 1) ? 1 : N - Nc + 1;
                 const double sl = wsb[oSLu + o], su = wsb[oSUu + o], zl = wsb[oZLu + o], zu = wsb[oZUu + o], u = wsb[oU + o];
-                const double vl = mu / sl - zl / sl * ((u - lbu[o]) - sl), vu = mu / su - zu / su * ((ubu[o] - u) - su);
+                const double vl = qdiv(mu, sl) - qdiv(zl, sl) * ((u - lbu[o]) - sl), vu = qdiv(mu, su) - qdiv(zu, su) * ((ubu[o] - u) - su);
                 SC[j * 16 + e] = u;
-                SC[j * 16 + 2 + e] = cnt * 2 * P.r[e] + zl / sl + zu / su;
+                SC[j * 16 + 2 + e] = cnt * 2 * P.r[e] + qdiv(zl, sl) + qdiv(zu, su);
                 SC[j * 16 + 4 + e] = cnt * 2 * P.r[e] * u - (vl - vu);
             }
             __syncthreads();
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                                 double sx, sy;
                                 const double gg = gdist(m, x, y, sx, sy), dd = sx * d0 + sy * d1 + (gg - d[u]);
                                 SV(odV, k, 3 + m) = dd;
-                                if (k < N && lw != 0.0) dphi_f += -2.0 * lw / (d[u] * d[u] * d[u]) * dd;
+                                if (k < N && lw != 0.0) dphi_f += qdiv(-2.0 * lw, d[u] * d[u] * d[u]) * dd;
                                 const double v = -(gv[u] + wd[u] * dd);
                                 RV(oetan, k, m) = v; mult_max = fmax(mult_max, fabs(v));
                             }
@@ -779,10 +794,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             double a_p = 1.0, a_d = 1.0, dphi = dphi_f, thh = 0.0;
             LogSum lgs_;
             auto slot = [&](double s_, double z_, double h_, double jd_) {
-                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
-                if (ds_ < 0.0) a_p = fmin(a_p, -tau * s_ / ds_);
-                if (dz_ < 0.0) a_d = fmin(a_d, -tau * z_ / dz_);
-                dphi -= mu * ds_ / s_; lgs_.add(s_); thh += fabs(h_ - s_);
+                const double ds_ = jd_ + (h_ - s_), dz_ = qdiv(mu - s_ * z_ - z_ * ds_, s_);
+                if (ds_ < 0.0) a_p = fmin(a_p, qdiv(-tau * s_, ds_));
+                if (dz_ < 0.0) a_d = fmin(a_d, qdiv(-tau * z_, dz_));
+                dphi -= qdiv(mu * ds_, s_); lgs_.add(s_); thh += fabs(h_ - s_);
             };
             {
                 auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double zl, double su, double zu) {
@@ -865,10 +880,10 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
             // ---- G. accept: duals and slacks (they need the old primal point), then the primal point
             auto upd = [&](double s_, double z_, double h_, double jd_, double &sn_, double &zo_) {
-                const double ds_ = jd_ + (h_ - s_), dz_ = (mu - s_ * z_ - z_ * ds_) / s_;
+                const double ds_ = jd_ + (h_ - s_), dz_ = qdiv(mu - s_ * z_ - z_ * ds_, s_);
                 sn_ = s_ + alpha * ds_;
                 const double zn_ = z_ + a_d * dz_;
-                zo_ = fmin(fmax(zn_, mu / (1e10 * sn_)), 1e10 * mu / sn_);
+                zo_ = fmin(fmax(zn_, qdiv(1e-10 * mu, sn_)), qdiv(1e10 * mu, sn_));
             };
             {
                 auto item = [&](int e, double v, double dv, double lo, double hi, double sl, double zl, double su, double zu) {

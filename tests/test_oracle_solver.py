@@ -170,11 +170,11 @@ def test_ipopt_defaults_variant_and_basin_sensitivity(tmp_path):
     """the oracle's IPOPT-faithful variant (NMPC_ORACLE_IPOPT_DEFAULTS=1: mu_init 0.1, filter line search of Waechter &
     Biegler alg. A, independent dual step, no cold-start retry) against the shipped algorithm on the same seeded bench instances — the only
     available estimate of how often the reference's IPOPT would end at another KKT point of this non-convex NLP.  256 instances per team size
-    here (docs/basin_sensitivity_r3.jsonl holds the 1024-instance run of tools/basin_sensitivity.py: same point on 97.8 % / 55.3 % / 71.4 %
+    here (docs/basin_sensitivity_r4.jsonl holds the 1024-instance run of tools/basin_sensitivity.py on round 4's algorithm: same point on 97.8 % / 50.6 % / 70.8 %; round 3: 97.8 % / 55.3 % / 71.4 %
     of the two / six / ten-robot instances; where the points differ the objectives do by a median 0.1-0.7 %, and neither variant is
     systematically lower).  Asserted: both variants converge everywhere, two robots agree almost always, a different end point is a
     different LOCAL MINIMUM of similar quality (not a failure), and the literal C2 set ends at the same point, the literal, perfectly
-    symmetric C6 swap at the same objective (its mirror image)."""
+    symmetric C6 swap at two local minima of similar quality (550.93 / 552.88; round 3: mirror images of one)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import basin_sensitivity as BS
