@@ -481,6 +481,19 @@ def main():
             dca = np.max(np.abs(r["x"][:n_ca].cpu().numpy() - ref_ca["x"]), axis=1)
             out["casadi"] = {"version": what_ca, "value": 1.0 / float(ref_ca["seconds"].mean()), "unit": "solves/s", "cores": 1, "kind": "casadi-ipopt (own generator, C6:345 options)",
                              "sample": "first %d instances, one thread" % n_ca, "same_point_frac_vs_gpu": float((dca <= 1e-6).mean()), "return_status": sorted(set(ref_ca["return_status"]))}
+    # LAST key: a digest of everything above in a few hundred characters — a record that keeps only the tail of this line still holds every
+    # sweep entry (solves/s, roofline fraction, traffic), the closed-loop and host-buffer rates, the CPU baseline and the casadi probe
+    dg = {"six_B%d" % B: [round(value), round(out["roofline"]["frac"], 4), round(out["roofline"].get("traffic_GBps") or 0)]}
+    for s_ in out.get("sweep", []):
+        dg["%s_B%d" % (s_["workload"].split(":")[0], s_["batch"])] = [round(s_["value"]), round(s_["roofline"]["frac"], 4), round(s_["roofline"].get("traffic_GBps") or 0), int(s_["max_iters"])]
+    for k_ in ("closed_loop", "host_buffers"):
+        if k_ in out:
+            dg[k_] = round(out[k_]["solves_per_s"])
+    if "cpu_baseline" in out:
+        dg["cpu_baseline"] = [round(out["cpu_baseline"]["value"]), out["cpu_baseline"]["cores"]]
+    dg["casadi"] = "not importable" if isinstance(out.get("casadi"), str) else (out.get("casadi") or "not probed")
+    dg["legend"] = "workload_batch: [solves/s, frac of 78.6 TFLOP/s fp64, HBM-side GB/s (0 = no matching profile), max iterations]"
+    out["digest"] = dg
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -27,7 +27,9 @@
 /* Cold-start retry (restoration of last resort): a solve that stalls after its barrier restarts, fails numerically or is
    still iterating NMPC_COLD_RETRY_ITERS iterations into an attempt is restarted from the reference's cold start X_k = x0, U = 0
    (C6:398-400; LIDAR: V4:184-196), at most NMPC_COLD_RETRIES times, the second time with a ten times larger initial barrier parameter. */
+#ifndef NMPC_COLD_RETRY_ITERS
 #define NMPC_COLD_RETRY_ITERS 500
+#endif
 #define NMPC_COLD_RETRIES 2
 
 /* Slack of the stage-0 feasibility pre-check (status 3): a measured x0 that violates a pair / obstacle row by less than this — the
