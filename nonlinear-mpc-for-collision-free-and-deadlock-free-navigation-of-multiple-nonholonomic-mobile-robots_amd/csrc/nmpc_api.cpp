@@ -81,6 +81,7 @@ static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
     P->pad_rows = c->pad_rows; P->pad_value = c->pad_value; P->max_iter = c->max_iter;
     P->T = c->T; P->dmin2 = c->dmin * c->dmin; P->vmax = c->v_max; P->wmax = c->w_max; P->xymax = c->xy_max; P->thmax = c->th_max;
     P->robdim = c->rob_dim; P->margin = c->margin; P->tol = c->tol; P->mu_init = c->mu_init;
+    P->rho_el = NMPC_ELASTIC_RHO;
     for (int d = 0; d < 3; d++) P->q[d] = c->q[d];
     for (int d = 0; d < 2; d++) P->r[d] = c->r[d];
     memcpy(P->obs, c->obs, sizeof(P->obs));
@@ -93,6 +94,7 @@ static int fill_params(const nmpc_config_t *c, nmpc::KParams *P)
     P->oSN = take((int64_t)N * m); P->oCS = take((int64_t)N * m); P->oC = take(nX); P->oH = take(nH); P->oGX = take(nX);
     P->oHUU = take(nU); P->oGU = take(nU); P->oHVT = take((int64_t)N * m); P->oHTT = take((int64_t)N * m);
     P->oKG = take((int64_t)N * nu * nx); P->oKFF = take(nU);
+    P->oEL = take(2 * nH);  // elastic variables of the HBM-resident kernel and their steps (one per inequality slot; only the pair / obstacle slots are used)
     P->oCKP = take((int64_t)((N - 1) / NMPC_CKPT_EVERY + 1) * (nx * nx + nx));      // saved cost-to-go of the backward sweep (partial re-factorisation)
     P->stride = o;
     return 0;
@@ -152,6 +154,11 @@ int32_t nmpc_create_opts(const nmpc_config_t *cfg, int32_t max_batch, const nmpc
         const int64_t slots = (cfg->N - 1) / NMPC_CKPT_EVERY + 1;
         h->P.oCKPT = h->P.stride2;
         h->P.stride2 += slots * (3 * cfg->m + 1) * 64;
+    }
+    {   // elastic variables t of the pair and obstacle rows (elastic phase only)
+        const int64_t N1 = cfg->N + 1, m = cfg->m, el = N1 * (m * (m - 1) / 2 + m * cfg->n_obs);
+        h->P.oELAS = h->P.stride2;
+        h->P.stride2 += (el + 15) / 16 * 16;
     }
     int64_t per = h->kernel == 1 ? h->P.stride : h->P.stride2;
     h->ws_bytes = (int64_t)sizeof(double) * per * max_batch;

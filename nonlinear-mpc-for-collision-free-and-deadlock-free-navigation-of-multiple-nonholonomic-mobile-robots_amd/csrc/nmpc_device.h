@@ -16,6 +16,7 @@ struct KParams {
     int32_t o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;     // inequality slot offsets inside one stage block
     double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin, pad_value, tol, mu_init;
     double q[3], r[2];
+    double rho_el;        // penalty of the elastic phase (NMPC_ELASTIC_RHO)
     double obs[3 * NMPC_MAX_OBSTACLES];
     // per-instance workspace carve-up, in doubles
     int64_t stride;
@@ -26,8 +27,9 @@ struct KParams {
     int64_t stride2;      // workspace stride of the LDS-resident kernel (stage packs + transposed gains)
     int64_t oPACK, oKT;
     int64_t oCKPT;        // LDS-resident kernels: cost-to-go saved every NMPC_CKPT_EVERY stages of the backward sweep, [(N-1)/NMPC_CKPT_EVERY + 1] slots of (3m + 1) * 64 doubles
+    int64_t oELAS;        // LDS-resident kernels: elastic variables t of the pair and obstacle rows, [(N+1) * (NP + m K)]: touched only in the elastic phase
     int64_t oDUAL;        // column kernel: slacks and duals of the inequality rows (touched by the stage-parallel phases only) live here, not in LDS
-    int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF, oCKP;      // oCKP: the HBM-resident kernel's saved cost-to-go, [(N-1)/NMPC_CKPT_EVERY + 1][nx * nx + nx]
+    int32_t oX, oU, oLAM, oS, oZ, oDX, oDU, oLAMN, oDS, oDZ, oSN, oCS, oC, oH, oGX, oHUU, oGU, oHVT, oHTT, oKG, oKFF, oCKP, oEL;      // oCKP: the HBM-resident kernel's saved cost-to-go, [(N-1)/NMPC_CKPT_EVERY + 1][nx * nx + nx]; oEL: its elastic variables, one per inequality slot
 };
 
 hipError_t launch_solve(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,

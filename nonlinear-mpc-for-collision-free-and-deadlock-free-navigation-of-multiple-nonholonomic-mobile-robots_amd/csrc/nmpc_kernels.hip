@@ -185,6 +185,10 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     double *base = ws + inst * P.stride;
     double *X = base + P.oX, *U = base + P.oU, *LAM = base + P.oLAM, *S = base + P.oS, *Z = base + P.oZ;
     double *DX = base + P.oDX, *DU = base + P.oDU, *LAMN = base + P.oLAMN, *DS = base + P.oDS, *DZ = base + P.oDZ;
+    double *EL = base + P.oEL, *DEL = EL + (size_t)(P.N + 1) * P.nh;      // elastic variables t and their steps (elastic phase only; pair / obstacle slots)
+    const double rho = P.rho_el;
+    bool el = false;      // elastic phase: the second restart of last resort (oracle/nmpc_oracle.c has the derivation)
+#define ELSLOT(s) (el && (s) >= P.o_pr)
     double *SN = base + P.oSN, *CS = base + P.oCS, *Cd = base + P.oC, *H = base + P.oH, *GX = base + P.oGX;
     double *HUU = base + P.oHUU, *GU = base + P.oGU, *HVT = base + P.oHVT, *HTT = base + P.oHTT;
     double *KG = base + P.oKG, *KFF = base + P.oKFF;
@@ -295,6 +299,8 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                     double st = S[k * NH + s] + a * DS[k * NH + s];
                     double h = slot_h<M_>(P, sPi, sPj, k, s, sX, sU);
                     lg += log(st);
+                    if (ELSLOT(s)) { const double tt = EL[k * NH + s] + a * DEL[k * NH + s]; lg += log(tt); fs += rho * tt; th += fabs(h + tt - st); }
+                    else
                     th += fabs(h - st);
                 }
         }
@@ -313,6 +319,8 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             int k = e / NH, s = e - k * NH;
             if (!slot_active(P, k, s)) { S[e] = 1.0; Z[e] = 0.0; continue; }
             double fl = (s < P.o_xl) ? 1e-12 : bp;
+            DEL[e] = 0.0;
+            if (ELSLOT(s)) { const double tv = fmax(bp, bp - H[e]), sv = H[e] + tv; EL[e] = tv; S[e] = sv; Z[e] = fmin(mu / sv, 0.5 * rho); continue; }
             double sv = fmax(H[e], fl);
             S[e] = sv; Z[e] = mu / sv;
         }
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
     // (C6:398-400; the cold-start retry of NMPC_COLD_RETRY_ITERS): interior push, slacks onto the constraint values, duals mu/s, multipliers 0
     int n_cold = 0, it_base = 0;
     auto do_restart = [&](bool cold) {
-        if (cold) { n_cold++; it_base = iter; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; }
+        if (cold) { n_cold++; it_base = iter; el = n_cold >= 2; mu = P.mu_init; n_tiny = 0; n_restart = 0; }      // the second restart of last resort is the elastic phase
         for (int e = tid + NX; e < (N + 1) * NX; e += TPB) {
             if (cold) X[e] = X[e % NX];
             const int d = (e % NX) % 3;
@@ -385,6 +393,8 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
             int k = e / NH, s = e - k * NH;
             if (slot_active(P, k, s)) {
                 double sv = S[e], zv = Z[e];
+                if (ELSLOT(s)) { const double pt = EL[e] * (rho - zv); e_h = fmax(e_h, fabs(H[e] + EL[e] - sv)); szmax = fmax(szmax, pt); szmin = fmin(szmin, pt); }
+                else
                 e_h = fmax(e_h, fabs(H[e] - sv));
                 zsum += zv;
                 szmax = fmax(szmax, sv * zv); szmin = fmin(szmin, sv * zv);
@@ -399,7 +409,15 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
         kkt = E0;
         if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && iter < P.max_iter) { do_restart(true); continue; } status = NMPC_STATUS_NUMERIC; break; }
-        if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (E0 <= P.tol) {
+            status = NMPC_STATUS_CONVERGED;
+            if (el) {       // the penalty problem's solution solves the NLP only if every elastic variable has closed
+                double tmax = 0.0;
+                for (int e = tid; e < (N + 1) * NH; e += TPB) { int k = e / NH, s = e - k * NH; if (s >= P.o_pr && slot_active(P, k, s)) tmax = fmax(tmax, EL[e]); }
+                if (blk_max<TPB>(tmax, sRed) > NMPC_X0_TOL) status = NMPC_STATUS_STALLED;
+            }
+            break;
+        }
         if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
         if (n_cold < NMPC_COLD_RETRIES && iter - it_base >= NMPC_COLD_RETRY_ITERS) { do_restart(true); continue; }
         // ================= monotone barrier update (IPOPT eq. 7)
@@ -425,7 +443,10 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 }
                 const double *sk = S + k * NH, *zk = Z + k * NH, *hk = H + k * NH;
                 double j0, j1, j2;
-                jxT_robot<M_>(P, k, i, x, [&](int s) { double sv = sk[s], zv = zk[s]; return mu / sv - zv / sv * (hk[s] - sv); }, j0, j1, j2);
+                jxT_robot<M_>(P, k, i, x, [&](int s) {
+                    double sv = sk[s], zv = zk[s];
+                    if (ELSLOT(s)) { const double rz = rho - zv, D_ = sv / zv + EL[k * NH + s] / rz, q_ = hk[s] - mu / zv + mu / rz; return zv - q_ / D_; }
+                    return mu / sv - zv / sv * (hk[s] - sv); }, j0, j1, j2);
                 g0 -= j0; g1 -= j1; g2 -= j2;
             }
             GX[k * NX + 3 * i] = g0; GX[k * NX + 3 * i + 1] = g1; GX[k * NX + 3 * i + 2] = g2;
@@ -514,6 +535,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                         int i = sPi[q], j = sPj[q];
                         double dx = sX[3 * i] - sX[3 * j], dy = sX[3 * i + 1] - sX[3 * j + 1];
                         double zz = P.pairs ? Z[k * NH + P.o_pr + q] : 0.0, sg = P.pairs ? zz / S[k * NH + P.o_pr + q] : 0.0;
+                        if (el && P.pairs) sg = 1.0 / (S[k * NH + P.o_pr + q] / zz + EL[k * NH + P.o_pr + q] / (rho - zz));
                         sE[3 * q] = 4 * sg * dx * dx - 2 * zz; sE[3 * q + 1] = 4 * sg * dx * dy; sE[3 * q + 2] = 4 * sg * dy * dy - 2 * zz;
                     }
                 }
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                             double dx = sX[3 * i] - P.obs[3 * o], dy = sX[3 * i + 1] - P.obs[3 * o + 1];
                             double rr = sqrt(dx * dx + dy * dy), n0 = dx / rr, n1 = dy / rr;
                             int sl = k * NH + P.o_ob + i * P.K + o;
-                            double sg = Z[sl] / S[sl], zz = Z[sl] / rr;
+                            double sg = el ? 1.0 / (S[sl] / Z[sl] + EL[sl] / (rho - Z[sl])) : Z[sl] / S[sl], zz = Z[sl] / rr;
                             e00 += sg * n0 * n0 - zz * (1 - n0 * n0);
                             e01 += sg * n0 * n1 + zz * n0 * n1;
                             e11 += sg * n1 * n1 - zz * (1 - n1 * n1);
@@ -702,8 +724,19 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 int e = k * NH + s;
                 if (!slot_active(P, k, s)) { DS[e] = 0.0; DZ[e] = 0.0; continue; }
                 double sv = S[e], zv = Z[e];
-                double ds = slot_jd<M_>(P, sPi, sPj, k, s, x, dxk, duk) + (H[e] - sv);
-                double dz = (mu - sv * zv - zv * ds) / sv;
+                double ds, dz;
+                if (ELSLOT(s)) {
+                    const double tv = EL[e], rz = rho - zv, D_ = sv / zv + tv / rz, q_ = H[e] - mu / zv + mu / rz;
+                    dz = -(slot_jd<M_>(P, sPi, sPj, k, s, x, dxk, duk) + q_) / D_;
+                    ds = (mu - sv * zv - sv * dz) / zv;
+                    const double dt = (mu - tv * rz + tv * dz) / rz;
+                    DEL[e] = dt;
+                    if (dt < 0.0) a_p = fmin(a_p, -tau * tv / dt);
+                    if (dz > 0.0) a_d = fmin(a_d, tau * rz / dz);
+                } else {
+                ds = slot_jd<M_>(P, sPi, sPj, k, s, x, dxk, duk) + (H[e] - sv);
+                dz = (mu - sv * zv - zv * ds) / sv;
+                }
                 DS[e] = ds; DZ[e] = dz;
                 if (s >= P.o_pr) mult_max = fmax(mult_max, fabs(zv + dz));
                 if (ds < 0.0) a_p = fmin(a_p, -tau * sv / ds);
@@ -771,7 +804,7 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
         }
         for (int e = tid; e < (N + 1) * NH; e += TPB) {
             int k = e / NH, s = e - k * NH;
-            if (slot_active(P, k, s)) dphi -= mu * DS[e] / S[e];
+            if (slot_active(P, k, s)) { dphi -= mu * DS[e] / S[e]; if (ELSLOT(s)) dphi += (rho - mu / EL[e]) * DEL[e]; }
         }
         dphi = blk_sum<TPB>(dphi, sRed);
         for (int e = NX + tid; e < (N + 1) * NX; e += TPB) mult_max = fmax(mult_max, fabs(LAMN[e]));
@@ -812,7 +845,9 @@ __global__ __launch_bounds__(TPB) void solve_kernel(const KParams P, const doubl
                 double sv = S[e] + alpha * DS[e];
                 double zv = Z[e] + a_d * DZ[e];
                 S[e] = sv;
-                Z[e] = fmin(fmax(zv, mu / (1e10 * sv)), 1e10 * mu / sv);
+                double hi = 1e10 * mu / sv;
+                if (ELSLOT(s)) { const double tn = EL[e] + alpha * DEL[e]; EL[e] = tn; hi = fmin(hi, rho - mu / (1e10 * tn)); }
+                Z[e] = fmin(fmax(zv, mu / (1e10 * sv)), hi);
             }
         }
         __syncthreads();

@@ -50,6 +50,9 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #ifndef NMPC_COL_WAVES_MID
 #define NMPC_COL_WAVES_MID 1        // occupancy the compiler is ASKED for, four to six robots (see col_min_waves)
 #endif
+#ifndef NMPC_COL_WAVES_LAT
+#define NMPC_COL_WAVES_LAT 2        // five / six robots, latency shape, no heading bound: with the elastic phase's code the allocator, asked for 1, lands on 255 VGPRs + 2 AGPRs = 258 > 256, i.e. ONE wave per SIMD (warm closed loop 364 k -> 256 k solves/s); asked for 2 it must stay within 256
+#endif
 #ifndef NMPC_COL_DUMMY_ST
 #define NMPC_COL_DUMMY_ST (NU - 1)
 #endif
@@ -75,7 +78,7 @@ constexpr bool rp_live(int i, int jj, int nc, int nu) { return i >= nc || (4 * (
 // +2.5 %, 16384 +3 %.  The one variant that lands above 256 when asked for 1 (four robots, heading bounds, slacks in the workspace: 257) keeps 2.
 constexpr int col_min_waves(int m, int thb, int dl)
 {
-    return m > 6 ? 1 : (m <= 3 ? NMPC_COL_WAVES_SMALL : ((m == 4 && thb && !dl) ? 2 : NMPC_COL_WAVES_MID));
+    return m > 6 ? 1 : (m <= 3 ? NMPC_COL_WAVES_SMALL : ((m == 4 && thb && !dl) ? 2 : ((m >= 5 && !thb && dl) ? NMPC_COL_WAVES_LAT : NMPC_COL_WAVES_MID)));
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -140,6 +143,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     const int N = P.N, N1 = P.N + 1, K = P.K, MK = M_ * P.K;
     const double T = P.T;
     const size_t inst = (P.order && *P.order_bad == 0) ? (size_t)P.order[blockIdx.x] : (size_t)blockIdx.x;      // dispatch-order hint: long solves first (ignored unless it is a permutation)
+    double mu = P.mu_init;                         // barrier parameter (declared here: the merit function of the elastic phase needs it)
+    bool el = false;                               // elastic phase (the second restart of last resort): pair / obstacle rows h + t - s = 0 with penalty rho t
     const bool prs = P.pairs != 0;                 // pair rows present (the no-pair multi-robot NLP keeps NP slots that are never touched)
     const int NPA = prs ? G::NP : 0;
 
@@ -176,6 +181,9 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    double *TPp = ws + inst * P.stride2 + P.oELAS;     // [N1*NP]   elastic variables of the pair rows (elastic phase only; always in the workspace)
+    double *TOb = TPp + N1 * NP;                       // [N1*MK]   ... of the obstacle rows
+    const double rho = P.rho_el;
     double *gck = ws + inst * P.stride2 + P.oCKPT;     // [(N-1)/NMPC_CKPT_EVERY + 1][NX + 1][64]  saved cost-to-go of the backward sweep (column-per-lane registers as they are)
     const double *pp = p_in + inst * (2 * NX);
     const double *wi = w0 + inst * (size_t)P.nvar;
@@ -276,7 +284,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     };
     // ---- merit pieces at (X + a DX, U + a DU, S + a DS): objective, sum log s, l1 infeasibility, max defect / slack residual.
     //      a == 0 evaluates the current point.  Every inequality row carries an explicit slack.
-    auto merit = [&](double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
+    auto merit_t = [&](auto elc, double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
+        constexpr bool EL = decltype(elc)::value;      // elastic phase: a separate instantiation, the plain one carries no trace of it
         double fs = 0.0, t = 0.0, mc = 0.0, mh = 0.0;
         LogSum ls;      // sum of log(slack): mantissa product and exponent sum per lane, ONE logarithm per wavefront at the end (nmpc_solve_common.h)
         // one bound row: current slack sv, current value h0, step of the value jd, trial value ht
@@ -317,13 +326,21 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double dx = (X[oi] + a * DX[oi]) - (X[oj] + a * DX[oj]), dy = (X[oi + 1] + a * DX[oi + 1]) - (X[oj + 1] + a * DX[oj + 1]);
             double h = h_pair(dx, dy, P.dmin2);
             // trial slack: s + a ds, ds = J dx + (h0 - s)
-            double sv = SPp[k * NP + q];
-            if (a != 0.0) {
+            double sv = SPp[k * NP + q], tv = 0.0;
+            if constexpr (EL) {       // elastic row: s and t both move, the penalty rho t joins the objective
+                tv = TPp[k * NP + q];
+                if (a != 0.0) {
+                    double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], ds, dz, dt;
+                    el_step(mu, rho, sv, ZPp[k * NP + q], tv, h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1]), ds, dz, dt);
+                    sv += a * ds; tv += a * dt;
+                }
+                ls.add(tv); fs += rho * tv;
+            } else if (a != 0.0) {
                 double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1];
                 sv += a * ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             }
             ls.add(sv);
-            double r = fabs(h - sv);
+            double r = fabs(h - sv + tv);
             t += r; mh = fmax(mh, r);
         }
         for (int it = tid; it < (N - 1) * MK; it += TPB) {
@@ -331,17 +348,28 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             const int oi = k * NX + 3 * i;
             double px = X[oi] + a * DX[oi], py = X[oi + 1] + a * DX[oi + 1];
             double h = h_obs(r_obs(px - P.obs[3 * o], py - P.obs[3 * o + 1]), P.robdim, P.obs[3 * o + 2], P.margin);
-            double sv = SO[k * MK + e];
-            if (a != 0.0) {
+            double sv = SO[k * MK + e], tv = 0.0;
+            if constexpr (EL) {
+                tv = TOb[k * MK + e];
+                if (a != 0.0) {
+                    double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), ds, dz, dt;
+                    el_step(mu, rho, sv, ZO[k * MK + e], tv, h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1]), ds, dz, dt);
+                    sv += a * ds; tv += a * dt;
+                }
+                ls.add(tv); fs += rho * tv;
+            } else if (a != 0.0) {
                 double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey);
                 sv += a * ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             }
             ls.add(sv);
-            double r = fabs(h - sv);
+            double r = fabs(h - sv + tv);
             t += r; mh = fmax(mh, r);
         }
         fv = wsum<TPB>(fs, RED); lg = wlogsum<TPB>(ls, RED); th = wsum<TPB>(t, RED);
         ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
+    };
+    auto merit = [&](double a, double &fv, double &lg, double &th, double &ec_, double &eh_) {
+        if (el) merit_t(std::true_type{}, a, fv, lg, th, ec_, eh_); else merit_t(std::false_type{}, a, fv, lg, th, ec_, eh_);
     };
 
     // ---- constant entries of the stage packs (the T and zero slots, stage 0's pair blocks): once per solve
@@ -352,7 +380,6 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     for (int q = tid; q < 3 * NP; q += TPB) gpack[G::PK_E + q] = 0.0;     // stage 0 carries no pair rows
     if (!prs)                                                              // no pair rows at all: the E slots of every stage are zero
         for (int e = tid; e < (N - 1) * 3 * NP; e += TPB) gpack[(size_t)(1 + e / (3 * NPd)) * G::PACK + G::PK_E + e % (3 * NPd)] = 0.0;
-    double mu = P.mu_init;
     // ---- slacks and duals from the current primal point (also the barrier restart after a stall)
     auto init_barrier = [&]() {
         for (int it = tid; it < N1 * NP; it += TPB) {
@@ -360,8 +387,14 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             if (k >= 1 && k <= N - 1 && prs) {
                 int i, j; pair_ij(q, i, j);
                 double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-                double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
+                const double hv = h_pair(dx, dy, P.dmin2);
+                if (el) {       // t absorbs the violation: s = h + t >= bp, 0 < z < rho
+                    const double tv = fmax(bp, bp - hv), sv = hv + tv;
+                    TPp[it] = tv; SPp[it] = sv; ZPp[it] = fmin(mu / sv, 0.5 * rho);
+                } else {
+                double sv = fmax(hv, bp);
                 SPp[it] = sv; ZPp[it] = mu / sv;
+                }
             } else { SPp[it] = 1.0; ZPp[it] = 0.0; }
         }
         for (int it = tid; it < N1 * MK; it += TPB) {
@@ -369,8 +402,14 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             if (k >= 1 && k <= N - 1) {
                 int i = e / K, o = e - i * K;
                 double dx = X[k * NX + 3 * i] - P.obs[3 * o], dy = X[k * NX + 3 * i + 1] - P.obs[3 * o + 1];
-                double sv = fmax(h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin), bp);
+                const double hv = h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin);
+                if (el) {
+                    const double tv = fmax(bp, bp - hv), sv = hv + tv;
+                    TOb[it] = tv; SO[it] = sv; ZO[it] = fmin(mu / sv, 0.5 * rho);
+                } else {
+                double sv = fmax(hv, bp);
                 SO[it] = sv; ZO[it] = mu / sv;
+                }
             } else { SO[it] = 1.0; ZO[it] = 0.0; }
         }
         for (int e = tid; e < N * NU; e += TPB) {
@@ -509,6 +548,10 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double zv = ZO[MK + it], pz = SO[MK + it] * zv;
             zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
         }
+        if (el) {       // elastic phase: the products t (rho - z) of the elastic variables with their duals
+            for (int it = tid; it < (N - 1) * NPA; it += TPB) { const double pt = TPp[NP + it] * (rho - ZPp[NP + it]); szmax = fmax(szmax, pt); szmin = fmin(szmin, pt); }
+            for (int it = tid; it < (N - 1) * MK; it += TPB) { const double pt = TOb[MK + it] * (rho - ZO[MK + it]); szmax = fmax(szmax, pt); szmin = fmin(szmin, pt); }
+        }
 #ifdef NMPC_PROFILE
         { double my = e_d; double gm = wmax<TPB>(e_d, RED);
           if (prof_out && (int)inst == P.trace_inst && iter < 2040 && my == gm) {
@@ -522,9 +565,18 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
         double s_c = fmax(smax, zsum / fmax(n_ineq, 1.0)) / smax;
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
         kkt = E0;
-        auto cold_retry = [&]() { cold = true; n_cold++; it_base = iter; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
+        auto cold_retry = [&]() { cold = true; n_cold++; it_base = iter; restarting = true; el = n_cold >= 2; mu = P.mu_init; n_tiny = 0; n_restart = 0; };      // the second restart of last resort is the elastic phase (include/nmpc_constants.h)
         if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && iter < P.max_iter) cold_retry(); else status = NMPC_STATUS_NUMERIC; break; }
-        if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (E0 <= P.tol) {
+            status = NMPC_STATUS_CONVERGED;
+            if (el) {       // the penalty problem's solution solves the NLP only if every elastic variable has closed
+                double tmax = 0.0;
+                for (int it = tid; it < (N - 1) * NPA; it += TPB) tmax = fmax(tmax, TPp[NP + it]);
+                for (int it = tid; it < (N - 1) * MK; it += TPB) tmax = fmax(tmax, TOb[MK + it]);
+                if (wmax<TPB>(tmax, RED) > NMPC_X0_TOL) status = NMPC_STATUS_STALLED;
+            }
+            break;
+        }
         if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
         if (n_cold < NMPC_COLD_RETRIES && iter - it_base >= NMPC_COLD_RETRY_ITERS) { cold_retry(); break; }
         const double mu_min = P.tol / 10.0;
@@ -539,6 +591,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 
         // ============ B0. stage packs: everything of stage k that does not depend on the cost-to-go
         // (a) per (stage, robot): x-gradient, diagonal additions, cross terms, coefficients, defects
+        auto stage_packs = [&](auto elc) {
+        constexpr bool EL = decltype(elc)::value;      // elastic phase: its own instantiation (the plain one is the code of rounds 1-3)
         for (int it = tid; it < N1 * M_; it += TPB) {
             int k = it / M_, i = it - k * M_;
             const double *x = X + k * NX;
@@ -569,16 +623,18 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                             constexpr int p = decltype(pc)::value;
                             const int j = p + (p >= i ? 1 : 0);
                             double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
-                            double sv = sq[p], zv = zq[p], sg = qdiv(zv, sv);
-                            double v = qdiv(mu, sv) - sg * (h_pair(dx, dy, P.dmin2) - sv);
+                            double sv = sq[p], zv = zq[p], sg, v;
+                            if constexpr (EL) el_sigma(mu, rho, sv, zv, TPp[k * NP + pidx_any<M_>(i, j)], h_pair(dx, dy, P.dmin2), sg, v);
+                            else { sg = qdiv(zv, sv); v = qdiv(mu, sv) - sg * (h_pair(dx, dy, P.dmin2) - sv); }
                             g0 -= 2 * dx * v; g1 -= 2 * dy * v;
                             h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
                         });
                     }
                     for (int o = 0; o < K; o++) {
                         double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = qdiv(dx, rr), n1 = qdiv(dy, rr);
-                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg = qdiv(zv, sv), zz = qdiv(zv, rr);
-                        double v = qdiv(mu, sv) - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv);
+                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg, v, zz = qdiv(zv, rr);
+                        if constexpr (EL) el_sigma(mu, rho, sv, zv, TOb[k * MK + i * K + o], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sg, v);
+                        else { sg = qdiv(zv, sv); v = qdiv(mu, sv) - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv); }
                         g0 -= n0 * v; g1 -= n1 * v;
                         h0 += sg * n0 * n0 - zz * (1 - n0 * n0); hxy += sg * n0 * n1 + zz * n0 * n1; h1 += sg * n1 * n1 - zz * (1 - n1 * n1);
                     }
@@ -618,10 +674,14 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-            double zz = ZPp[k * NP + q], sg = qdiv(zz, SPp[k * NP + q]);
+            double zz = ZPp[k * NP + q], sg;
+            if constexpr (EL) { double v_; el_sigma(mu, rho, SPp[k * NP + q], zz, TPp[k * NP + q], h_pair(dx, dy, P.dmin2), sg, v_); }
+            else sg = qdiv(zz, SPp[k * NP + q]);
             double *pk = gpack + (size_t)k * G::PACK + G::PK_E + 3 * q;
             pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
         }
+        };
+        if (el) stage_packs(std::true_type{}); else stage_packs(std::false_type{});
         __syncthreads();
         PROF_T(2);
 
@@ -1202,6 +1262,16 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 #endif
             return zv + dz;
         };
+        auto fbe = [&](double sv, double zv, double tv, double hv, double jd) -> double {      // an elastic row: s, t >= 0, 0 < z < rho
+            double ds, dz, dt;
+            el_step(mu, rho, sv, zv, tv, hv, jd, ds, dz, dt);
+            if (ds < 0.0) a_p = fmin(a_p, qdiv(-tau * sv, ds));
+            if (dt < 0.0) a_p = fmin(a_p, qdiv(-tau * tv, dt));
+            if (dz < 0.0) a_d = fmin(a_d, qdiv(-tau * zv, dz));
+            if (dz > 0.0) a_d = fmin(a_d, qdiv(tau * (rho - zv), dz));
+            dphi_b += qdiv(ds, sv) + qdiv(dt, tv) - qdiv(rho, mu) * dt;      // -mu dphi_b = -mu (ds/s + dt/t) + rho dt: the penalty's part rides along (no second accumulator)
+            return zv + dz;
+        };
         for (int e = tid; e < N * NU; e += TPB) {
             int c = e % NU;
             double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e];
@@ -1212,6 +1282,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double v = X[k * NX + bst(s)], dv = DX[k * NX + bst(s)], b = bvl(s), sl = v + b, su = b - v;
             fb(sl, ZXL[k * NXB + s], dv + ((v + b) - sl)); fb(su, ZXU[k * NXB + s], -dv + ((b - v) - su));
         }
+        if (!el) {
         for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
@@ -1227,10 +1298,27 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             mult_max = fmax(mult_max, fabs(fb(sv, ZO[k * MK + e], ds)));
         }
+        } else {        // elastic phase: the same two loops over elastic rows
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1];
+            mult_max = fmax(mult_max, fabs(fbe(SPp[k * NP + q], ZPp[k * NP + q], TPp[k * NP + q], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1]))));
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey);
+            mult_max = fmax(mult_max, fabs(fbe(SO[k * MK + e], ZO[k * MK + e], TOb[k * MK + e], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1]))));
+        }
+        }
         a_p = wmin<TPB>(a_p, RED); a_d = wmin<TPB>(a_d, RED);
         PROF_T(5);
         // ============ F. multipliers of the QP: stage-parallel residuals, then the robot-local adjoint recursion in registers
         //   lam+_k = A_k^T lam+_{k+1} - (grad f_k + W_k dx_k + W_xu du_k) + Jx_k^T (z + dz)_k
+        auto multiplier_residuals = [&](auto elc) {
+        constexpr bool EL = decltype(elc)::value;
         for (int it = tid; it < N * M_; it += TPB) {
             int k = 1 + it / M_, i = it - (k - 1) * M_;
             const double *x = X + k * NX, *dx = DX + k * NX;
@@ -1256,9 +1344,15 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                         const int j = p + (p >= i ? 1 : 0);
                         double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
                         double ddx = dx[3 * i] - dx[3 * j], ddy = dx[3 * i + 1] - dx[3 * j + 1];
-                        double sv = sq[p], zv = zq[p];
+                        double sv = sq[p], zv = zq[p], znew;
+                        if constexpr (EL) {
+                            double ds, dz, dt;
+                            el_step(mu, rho, sv, zv, TPp[k * NP + pidx_any<M_>(i, j)], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, ddx, ddy), ds, dz, dt);
+                            znew = zv + dz;
+                        } else {
                         double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv);
-                        double znew = zv + dz_of(mu, sv, zv, ds);
+                        znew = zv + dz_of(mu, sv, zv, ds);
+                        }
                         l0 += 2 * ex * znew + 2 * zv * ddx;      // Jx^T (z+dz)  -  (-2 z (ddx))  [exact-Hessian term of the pair row]
                         l1 += 2 * ey * znew + 2 * zv * ddy;
                     });
@@ -1267,8 +1361,15 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
                     double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = qdiv(ex, rr), n1 = qdiv(ey, rr);
                     double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o];
                     double nd = n0 * dx[3 * i] + n1 * dx[3 * i + 1];
+                    double znew, zz = qdiv(zv, rr);
+                    if constexpr (EL) {
+                        double ds, dz, dt;
+                        el_step(mu, rho, sv, zv, TOb[k * MK + i * K + o], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1]), ds, dz, dt);
+                        znew = zv + dz;
+                    } else {
                     double ds = ds_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
-                    double znew = zv + dz_of(mu, sv, zv, ds), zz = qdiv(zv, rr);
+                    znew = zv + dz_of(mu, sv, zv, ds);
+                    }
                     l0 += n0 * znew + zz * (dx[3 * i] - n0 * nd);
                     l1 += n1 * znew + zz * (dx[3 * i + 1] - n1 * nd);
                 }
@@ -1282,6 +1383,8 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             }
             RV[k * NX + 3 * i] = l0; RV[k * NX + 3 * i + 1] = l1; RV[k * NX + 3 * i + 2] = l2;
         }
+        };
+        if (el) multiplier_residuals(std::true_type{}); else multiplier_residuals(std::false_type{});
         __syncthreads();
         for (int i = tid; i < M_; i += TPB) {
             double n0 = 0.0, n1 = 0.0, n2 = 0.0;
@@ -1409,6 +1512,13 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double z = zv + a_d * dz;
             return fmin(fmax(z, qdiv(1e-10 * mu, snew)), qdiv(1e10 * mu, snew));
         };
+        auto zupe = [&](double sv, double zv, double tv, double hv, double jd, double &snew, double &tnew) {      // an elastic row
+            double ds, dz, dt;
+            el_step(mu, rho, sv, zv, tv, hv, jd, ds, dz, dt);
+            snew = sv + alpha * ds; tnew = tv + alpha * dt;
+            double z = zv + a_d * dz;
+            return fmin(fmax(z, qdiv(1e-10 * mu, snew)), fmin(qdiv(1e10 * mu, snew), rho - qdiv(1e-10 * mu, tnew)));
+        };
         for (int e = tid; e < N * NU; e += TPB) {
             int c = e % NU;
             double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e], sn;
@@ -1422,6 +1532,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             ZXL[es] = zup(sl, ZXL[es], dv + ((v + b) - sl), sn);
             ZXU[es] = zup(su, ZXU[es], -dv + ((b - v) - su), sn);
         }
+        if (!el) {
         for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
@@ -1438,6 +1549,23 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
             double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             ZO[k * MK + e] = zup(sv, ZO[k * MK + e], ds, sn);
             SO[k * MK + e] = sn;
+        }
+        } else {        // elastic phase
+        for (int it = tid; it < (N - 1) * NPA; it += TPB) {
+            int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
+            pair_ij(q, i, j);
+            const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
+            double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sn, tn;
+            ZPp[k * NP + q] = zupe(SPp[k * NP + q], ZPp[k * NP + q], TPp[k * NP + q], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1]), sn, tn);
+            SPp[k * NP + q] = sn; TPp[k * NP + q] = tn;
+        }
+        for (int it = tid; it < (N - 1) * MK; it += TPB) {
+            int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
+            const int oi = k * NX + 3 * i;
+            double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sn, tn;
+            ZO[k * MK + e] = zupe(SO[k * MK + e], ZO[k * MK + e], TOb[k * MK + e], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1]), sn, tn);
+            SO[k * MK + e] = sn; TOb[k * MK + e] = tn;
+        }
         }
         __syncthreads();
         for (int e = tid; e < N1 * NX; e += TPB) { X[e] += alpha * DX[e]; if (e >= NX) LAM[e] += alpha * (RV[e] - LAM[e]); }

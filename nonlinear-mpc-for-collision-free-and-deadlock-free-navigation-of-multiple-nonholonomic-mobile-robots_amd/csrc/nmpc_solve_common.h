@@ -80,6 +80,23 @@ __device__ __forceinline__ double defect_th(double xn, double x, double T, doubl
 __device__ __forceinline__ double ds_bound(double jd, double hv, double sv) { return jd + (hv - sv); }
 __device__ __forceinline__ double dz_of(double mu, double sv, double zv, double ds) { return qdiv(fma(-zv, ds, fma(-sv, zv, mu)), sv); }
 
+// ---- elastic phase (the second restart of last resort; derivation in oracle/nmpc_oracle.c): a pair / obstacle row h + t - s = 0, s, t >= 0,
+// dual z in (0, rho).  jd = J dx of the row (ds_pair / ds_obs minus their (h - s) term).
+__device__ __forceinline__ double jd_pair(double ex, double ey, double ddx, double ddy) { return fma(2.0 * ex, ddx, (2.0 * ey) * ddy); }
+__device__ __forceinline__ double jd_obs(double ex, double ey, double rr, double d0, double d1) { return qdiv(fma(ex, d0, ey * d1), rr); }
+__device__ __forceinline__ void el_sigma(double mu, double rho, double sv, double zv, double tv, double hv, double &sg, double &v)
+{
+    const double rz = rho - zv, D = qdiv(sv, zv) + qdiv(tv, rz), q = hv - qdiv(mu, zv) + qdiv(mu, rz);
+    sg = qdiv(1.0, D); v = zv - q * sg;
+}
+__device__ __forceinline__ void el_step(double mu, double rho, double sv, double zv, double tv, double hv, double jd, double &ds, double &dz, double &dt)
+{
+    const double rz = rho - zv, D = qdiv(sv, zv) + qdiv(tv, rz), q = hv - qdiv(mu, zv) + qdiv(mu, rz);
+    dz = -qdiv(jd + q, D);
+    ds = qdiv(mu - sv * zv - sv * dz, zv);
+    dt = qdiv(mu - tv * rz + tv * dz, rz);
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (indices usable in `if constexpr`)
 template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
 {

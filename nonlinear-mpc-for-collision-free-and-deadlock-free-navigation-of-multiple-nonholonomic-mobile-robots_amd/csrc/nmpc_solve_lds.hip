@@ -82,6 +82,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
 
     double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    double *TPp = ws + inst * P.stride2 + P.oELAS;     // [N1*NP]  elastic variables of the pair rows (elastic phase only), obstacle rows behind them
+    double *TOb = TPp + N1 * NP;                       // [N1*MK]
+    const double rho = P.rho_el;
     double *gck = ws + inst * P.stride2 + P.oCKPT;     // saved cost-to-go [P | p] of the backward sweep, one slot of (NX + 1) * 64 doubles per NMPC_CKPT_EVERY stages
     const double *pp = p_in + inst * (2 * NX);
     const double *wi = w0 + inst * (size_t)P.nvar;
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
     }
 
     // pair (i,j) of flat index q
+    double mu = P.mu_init;      // barrier parameter (declared here: the merit function of the elastic phase needs it)
+    bool el = false;            // elastic phase (the second restart of last resort; oracle/nmpc_oracle.c, nmpc_solve_col.hip)
     auto pair_ij = [&](int q, int &i, int &j) { i = 0; while (q >= M_ - 1 - i) { q -= M_ - 1 - i; i++; } j = i + 1 + q; };
 
     // ---- trig cache of the current iterate
@@ -246,13 +251,21 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double dx = (X[oi] + a * DX[oi]) - (X[oj] + a * DX[oj]), dy = (X[oi + 1] + a * DX[oi + 1]) - (X[oj + 1] + a * DX[oj + 1]);
             double h = h_pair(dx, dy, P.dmin2);
             // trial slack: s + a ds, ds = J dx + (h0 - s)
-            double sv = SPp[k * NP + q];
-            if (a != 0.0) {
+            double sv = SPp[k * NP + q], tv = 0.0;
+            if (el) {
+                tv = TPp[k * NP + q];
+                if (a != 0.0) {
+                    double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], ds, dz, dt;
+                    el_step(mu, rho, sv, ZPp[k * NP + q], tv, h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1]), ds, dz, dt);
+                    sv += a * ds; tv += a * dt;
+                }
+                l += log(tv); fs += rho * tv;
+            } else if (a != 0.0) {
                 double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1];
                 sv += a * ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             }
             l += log(sv);
-            double r = fabs(h - sv);
+            double r = fabs(h - sv + tv);
             t += r; mh = fmax(mh, r);
         }
         for (int it = tid; it < (N - 1) * MK; it += TPB) {
@@ -260,20 +273,27 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             const int oi = k * NX + 3 * i;
             double px = X[oi] + a * DX[oi], py = X[oi + 1] + a * DX[oi + 1];
             double h = h_obs(r_obs(px - P.obs[3 * o], py - P.obs[3 * o + 1]), P.robdim, P.obs[3 * o + 2], P.margin);
-            double sv = SO[k * MK + e];
-            if (a != 0.0) {
+            double sv = SO[k * MK + e], tv = 0.0;
+            if (el) {
+                tv = TOb[k * MK + e];
+                if (a != 0.0) {
+                    double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), ds, dz, dt;
+                    el_step(mu, rho, sv, ZO[k * MK + e], tv, h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1]), ds, dz, dt);
+                    sv += a * ds; tv += a * dt;
+                }
+                l += log(tv); fs += rho * tv;
+            } else if (a != 0.0) {
                 double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey);
                 sv += a * ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             }
             l += log(sv);
-            double r = fabs(h - sv);
+            double r = fabs(h - sv + tv);
             t += r; mh = fmax(mh, r);
         }
         fv = wsum<TPB>(fs, RED); lg = wsum<TPB>(l, RED); th = wsum<TPB>(t, RED);
         ec_ = wmax<TPB>(mc, RED); eh_ = wmax<TPB>(mh, RED);
     };
 
-    double mu = P.mu_init;
     // ---- slacks and duals from the current primal point (also the barrier restart after a stall)
     auto init_barrier = [&]() {
         for (int it = tid; it < N1 * NP; it += TPB) {
@@ -281,8 +301,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (k >= 1 && k <= N - 1 && prs) {
                 int i, j; pair_ij(q, i, j);
                 double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-                double sv = fmax(h_pair(dx, dy, P.dmin2), bp);
-                SPp[it] = sv; ZPp[it] = mu / sv;
+                const double hv = h_pair(dx, dy, P.dmin2);
+                if (el) { const double tv = fmax(bp, bp - hv), sv = hv + tv; TPp[it] = tv; SPp[it] = sv; ZPp[it] = fmin(mu / sv, 0.5 * rho); }
+                else { double sv = fmax(hv, bp); SPp[it] = sv; ZPp[it] = mu / sv; }
             } else { SPp[it] = 1.0; ZPp[it] = 0.0; }
         }
         for (int it = tid; it < N1 * MK; it += TPB) {
@@ -290,8 +311,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (k >= 1 && k <= N - 1) {
                 int i = e / K, o = e - i * K;
                 double dx = X[k * NX + 3 * i] - P.obs[3 * o], dy = X[k * NX + 3 * i + 1] - P.obs[3 * o + 1];
-                double sv = fmax(h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin), bp);
-                SO[it] = sv; ZO[it] = mu / sv;
+                const double hv = h_obs(r_obs(dx, dy), P.robdim, P.obs[3 * o + 2], P.margin);
+                if (el) { const double tv = fmax(bp, bp - hv), sv = hv + tv; TOb[it] = tv; SO[it] = sv; ZO[it] = fmin(mu / sv, 0.5 * rho); }
+                else { double sv = fmax(hv, bp); SO[it] = sv; ZO[it] = mu / sv; }
             } else { SO[it] = 1.0; ZO[it] = 0.0; }
         }
         for (int e = tid; e < N * NU; e += TPB) {
@@ -423,10 +445,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         for (int it = tid; it < (N - 1) * NPA; it += TPB) {
             double zv = ZPp[NP + it], pz = SPp[NP + it] * zv;
             zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
+            if (el) { const double pt = TPp[NP + it] * (rho - zv); szmax = fmax(szmax, pt); szmin = fmin(szmin, pt); }
         }
         for (int it = tid; it < (N - 1) * MK; it += TPB) {
             double zv = ZO[MK + it], pz = SO[MK + it] * zv;
             zsum += zv; szmax = fmax(szmax, pz); szmin = fmin(szmin, pz);
+            if (el) { const double pt = TOb[MK + it] * (rho - zv); szmax = fmax(szmax, pt); szmin = fmin(szmin, pt); }
         }
 #ifdef NMPC_PROFILE
         { double my = e_d; double gm = wmax<TPB>(e_d, RED);
@@ -441,9 +465,18 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
         double s_c = fmax(smax, zsum / fmax(n_ineq, 1.0)) / smax;
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, szmax / s_c));
         kkt = E0;
-        auto cold_retry = [&]() { cold = true; n_cold++; it_base = iter; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
+        auto cold_retry = [&]() { cold = true; n_cold++; it_base = iter; restarting = true; el = n_cold >= 2; mu = P.mu_init; n_tiny = 0; n_restart = 0; };      // the second restart of last resort is the elastic phase
         if (!(E0 == E0)) { if (n_cold < NMPC_COLD_RETRIES && iter < P.max_iter) cold_retry(); else status = NMPC_STATUS_NUMERIC; break; }
-        if (E0 <= P.tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (E0 <= P.tol) {
+            status = NMPC_STATUS_CONVERGED;
+            if (el) {       // the penalty problem's solution solves the NLP only if every elastic variable has closed
+                double tmax = 0.0;
+                for (int it = tid; it < (N - 1) * NPA; it += TPB) tmax = fmax(tmax, TPp[NP + it]);
+                for (int it = tid; it < (N - 1) * MK; it += TPB) tmax = fmax(tmax, TOb[MK + it]);
+                if (wmax<TPB>(tmax, RED) > NMPC_X0_TOL) status = NMPC_STATUS_STALLED;
+            }
+            break;
+        }
         if (iter >= P.max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
         if (n_cold < NMPC_COLD_RETRIES && iter - it_base >= NMPC_COLD_RETRY_ITERS) { cold_retry(); break; }
         const double mu_min = P.tol / 10.0;
@@ -482,15 +515,17 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                         if (j == i) continue;
                         int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
                         double dx = xi - x[3 * j], dy = yi - x[3 * j + 1];
-                        double sv = SPp[k * NP + q], zv = ZPp[k * NP + q], sg = zv / sv;
-                        double v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv);
+                        double sv = SPp[k * NP + q], zv = ZPp[k * NP + q], sg, v;
+                        if (el) el_sigma(mu, rho, sv, zv, TPp[k * NP + q], h_pair(dx, dy, P.dmin2), sg, v);
+                        else { sg = zv / sv; v = mu / sv - sg * (h_pair(dx, dy, P.dmin2) - sv); }
                         g0 -= 2 * dx * v; g1 -= 2 * dy * v;
                         h0 += 4 * sg * dx * dx - 2 * zv; hxy += 4 * sg * dx * dy; h1 += 4 * sg * dy * dy - 2 * zv;
                     }
                     for (int o = 0; o < K; o++) {
                         double dx = xi - P.obs[3 * o], dy = yi - P.obs[3 * o + 1], rr = r_obs(dx, dy), n0 = dx / rr, n1 = dy / rr;
-                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg = zv / sv, zz = zv / rr;
-                        double v = mu / sv - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv);
+                        double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o], sg, v, zz = zv / rr;
+                        if (el) el_sigma(mu, rho, sv, zv, TOb[k * MK + i * K + o], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sg, v);
+                        else { sg = zv / sv; v = mu / sv - sg * (h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin) - sv); }
                         g0 -= n0 * v; g1 -= n1 * v;
                         h0 += sg * n0 * n0 - zz * (1 - n0 * n0); hxy += sg * n0 * n1 + zz * n0 * n1; h1 += sg * n1 * n1 - zz * (1 - n1 * n1);
                     }
@@ -535,7 +570,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             int k = 1 + it / NPd, q = it - (k - 1) * NP, i, j;
             pair_ij(q, i, j);
             double dx = X[k * NX + 3 * i] - X[k * NX + 3 * j], dy = X[k * NX + 3 * i + 1] - X[k * NX + 3 * j + 1];
-            double zz = ZPp[k * NP + q], sg = zz / SPp[k * NP + q];
+            double zz = ZPp[k * NP + q], sg;
+            if (el) { double v_; el_sigma(mu, rho, SPp[k * NP + q], zz, TPp[k * NP + q], h_pair(dx, dy, P.dmin2), sg, v_); }
+            else sg = zz / SPp[k * NP + q];
             double *pk = gpack + (size_t)k * G::PACK + G::PK_E + 3 * q;
             pk[0] = -(4 * sg * dx * dx - 2 * zz); pk[1] = -(4 * sg * dx * dy); pk[2] = -(4 * sg * dy * dy - 2 * zz);
         }
@@ -821,6 +858,17 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             if (dz < 0.0) a_d = fmin(a_d, -tau * zv / dz);
             return zv + dz;
         };
+        double dphi_el = 0.0;       // elastic phase: the rows' part of the merit derivative, -mu (ds/s + dt/t) + rho dt
+        auto fbe = [&](double sv, double zv, double tv, double hv, double jd) -> double {
+            double ds, dz, dt;
+            el_step(mu, rho, sv, zv, tv, hv, jd, ds, dz, dt);
+            if (ds < 0.0) a_p = fmin(a_p, -tau * sv / ds);
+            if (dt < 0.0) a_p = fmin(a_p, -tau * tv / dt);
+            if (dz < 0.0) a_d = fmin(a_d, -tau * zv / dz);
+            if (dz > 0.0) a_d = fmin(a_d, tau * (rho - zv) / dz);
+            dphi_el += rho * dt - mu * (ds / sv + dt / tv);
+            return zv + dz;
+        };
         for (int e = tid; e < N * NU; e += TPB) {
             int c = e % NU;
             double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e];
@@ -836,6 +884,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
             double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q];
+            if (el) { mult_max = fmax(mult_max, fabs(fbe(sv, ZPp[k * NP + q], TPp[k * NP + q], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1])))); continue; }
             double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             mult_max = fmax(mult_max, fabs(fb(sv, ZPp[k * NP + q], ds)));
         }
@@ -843,6 +892,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
             const int oi = k * NX + 3 * i;
             double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e];
+            if (el) { mult_max = fmax(mult_max, fabs(fbe(sv, ZO[k * MK + e], TOb[k * MK + e], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1])))); continue; }
             double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             mult_max = fmax(mult_max, fabs(fb(sv, ZO[k * MK + e], ds)));
         }
@@ -869,9 +919,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     int q = (i < j) ? pidx<M_>(i, j) : pidx<M_>(j, i);
                     double ex = xi - x[3 * j], ey = yi - x[3 * j + 1];
                     double ddx = dx[3 * i] - dx[3 * j], ddy = dx[3 * i + 1] - dx[3 * j + 1];
-                    double sv = SPp[k * NP + q], zv = ZPp[k * NP + q];
-                    double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv);
-                    double znew = zv + dz_of(mu, sv, zv, ds);
+                    double sv = SPp[k * NP + q], zv = ZPp[k * NP + q], znew;
+                    if (el) { double ds, dz, dt; el_step(mu, rho, sv, zv, TPp[k * NP + q], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, ddx, ddy), ds, dz, dt); znew = zv + dz; }
+                    else { double ds = ds_pair(ex, ey, ddx, ddy, P.dmin2, sv); znew = zv + dz_of(mu, sv, zv, ds); }
                     l0 += 2 * ex * znew + 2 * zv * ddx;      // Jx^T (z+dz)  -  (-2 z (ddx))  [exact-Hessian term of the pair row]
                     l1 += 2 * ey * znew + 2 * zv * ddy;
                 }
@@ -879,8 +929,9 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
                     double ex = xi - P.obs[3 * o], ey = yi - P.obs[3 * o + 1], rr = r_obs(ex, ey), n0 = ex / rr, n1 = ey / rr;
                     double sv = SO[k * MK + i * K + o], zv = ZO[k * MK + i * K + o];
                     double nd = n0 * dx[3 * i] + n1 * dx[3 * i + 1];
-                    double ds = ds_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
-                    double znew = zv + dz_of(mu, sv, zv, ds), zz = zv / rr;
+                    double znew, zz = zv / rr;
+                    if (el) { double ds, dz, dt; el_step(mu, rho, sv, zv, TOb[k * MK + i * K + o], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1]), ds, dz, dt); znew = zv + dz; }
+                    else { double ds = ds_obs(ex, ey, rr, dx[3 * i], dx[3 * i + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv); znew = zv + dz_of(mu, sv, zv, ds); }
                     l0 += n0 * znew + zz * (dx[3 * i] - n0 * nd);
                     l1 += n1 * znew + zz * (dx[3 * i + 1] - n1 * nd);
                 }
@@ -944,6 +995,7 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
             double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q];
+            if (el) continue;      // elastic rows: summed by the step-length pass (dphi_el)
             double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             dphi -= mu * ds / sv;
         }
@@ -951,9 +1003,11 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
             const int oi = k * NX + 3 * i;
             double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e];
+            if (el) continue;
             double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             dphi -= mu * ds / sv;
         }
+        dphi += dphi_el;
         dphi = wsum<TPB>(dphi, RED);
         const double phi0 = f - mu * lgs;
         if (th0 > 0.0) {
@@ -1006,6 +1060,13 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             double z = zv + a_d * dz;
             return fmin(fmax(z, mu / (1e10 * snew)), 1e10 * mu / snew);
         };
+        auto zupe = [&](double sv, double zv, double tv, double hv, double jd, double &snew, double &tnew) {      // an elastic row
+            double ds, dz, dt;
+            el_step(mu, rho, sv, zv, tv, hv, jd, ds, dz, dt);
+            snew = sv + alpha * ds; tnew = tv + alpha * dt;
+            double z = zv + a_d * dz;
+            return fmin(fmax(z, mu / (1e10 * snew)), fmin(1e10 * mu / snew, rho - mu / (1e10 * tnew)));
+        };
         for (int e = tid; e < N * NU; e += TPB) {
             int c = e % NU;
             double lo = lbu(c), u = U[e], du = DU[e], sl = SUL[e], su = SUU[e], sn;
@@ -1024,6 +1085,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             pair_ij(q, i, j);
             const int oi = k * NX + 3 * i, oj = k * NX + 3 * j;
             double ex = X[oi] - X[oj], ey = X[oi + 1] - X[oj + 1], sv = SPp[k * NP + q], sn;
+            if (el) {
+                double tn;
+                ZPp[k * NP + q] = zupe(sv, ZPp[k * NP + q], TPp[k * NP + q], h_pair(ex, ey, P.dmin2), jd_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1]), sn, tn);
+                SPp[k * NP + q] = sn; TPp[k * NP + q] = tn;
+                continue;
+            }
             double ds = ds_pair(ex, ey, DX[oi] - DX[oj], DX[oi + 1] - DX[oj + 1], P.dmin2, sv);
             ZPp[k * NP + q] = zup(sv, ZPp[k * NP + q], ds, sn);
             SPp[k * NP + q] = sn;
@@ -1032,6 +1099,12 @@ __global__ __launch_bounds__(TPB) void solve_lds_kernel(const KParams P, const d
             int k = 1 + it / MK, e = it - (k - 1) * MK, i = e / K, o = e - i * K;
             const int oi = k * NX + 3 * i;
             double ex = X[oi] - P.obs[3 * o], ey = X[oi + 1] - P.obs[3 * o + 1], rr = r_obs(ex, ey), sv = SO[k * MK + e], sn;
+            if (el) {
+                double tn;
+                ZO[k * MK + e] = zupe(sv, ZO[k * MK + e], TOb[k * MK + e], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), jd_obs(ex, ey, rr, DX[oi], DX[oi + 1]), sn, tn);
+                SO[k * MK + e] = sn; TOb[k * MK + e] = tn;
+                continue;
+            }
             double ds = ds_obs(ex, ey, rr, DX[oi], DX[oi + 1], h_obs(rr, P.robdim, P.obs[3 * o + 2], P.margin), sv);
             ZO[k * MK + e] = zup(sv, ZO[k * MK + e], ds, sn);
             SO[k * MK + e] = sn;

@@ -65,6 +65,9 @@ typedef struct {
                        0: rounds 1-3 (whole sweep again); 1, 2, 3, 5: the stage-local experiments of VERDICT r3 item 1 (tools/sreg_experiment.py; never shipped) */
     double sreg_beta;
     double *dl_k; int *ns_k; double *Psnap, *pvsnap; int sreg_J, sreg_C;   /* per-(stage, control) shift memory of the stage-local variants */
+    int el;         /* 1 while the solve is in its elastic phase (the second restart of last resort): pair / obstacle rows h + t - s = 0, t >= 0, penalty NMPC_ELASTIC_RHO t */
+    double rho;
+    double *El, *Elt, *dEl;      /* elastic variables t, trial, step */
     int max_restarts;   /* barrier restarts after a stall: 3 (as the HIP path); NMPC_ORACLE_MAX_RESTARTS overrides (fixture generation) */
     int o_ul, o_uu, o_xl, o_xu, o_pr, o_ob;
     double T, dmin2, vmax, wmax, xymax, thmax, robdim, margin;
@@ -114,6 +117,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     w->max_restarts = getenv("NMPC_ORACLE_MAX_RESTARTS") ? atoi(getenv("NMPC_ORACLE_MAX_RESTARTS")) : 3;
     w->sreg = getenv("NMPC_ORACLE_STAGE_REG") ? atoi(getenv("NMPC_ORACLE_STAGE_REG")) : -1;
     w->sreg_beta = getenv("NMPC_ORACLE_SREG_BETA") ? atof(getenv("NMPC_ORACLE_SREG_BETA")) : 1e-4;
+    w->rho = NMPC_ELASTIC_RHO; w->el = 0;
     w->pc = getenv("NMPC_ORACLE_PC") ? atoi(getenv("NMPC_ORACLE_PC")) : 0;
     w->ipopt = getenv("NMPC_ORACLE_IPOPT_DEFAULTS") ? atoi(getenv("NMPC_ORACLE_IPOPT_DEFAULTS")) : 0;
     w->nxb = m * (w->thb ? 3 : 2);
@@ -144,7 +148,7 @@ static ws_t *ws_new(const nmpc_config_t *c)
     AL(sn, (size_t)N * m); AL(cs, (size_t)N * m); AL(snt, (size_t)N * m); AL(cst, (size_t)N * m);
     AL(C, nX); AL(Ct, nX); AL(H, nH); AL(Ht, nH);
     AL(Hxx, (size_t)(N + 1) * w->nx * w->nx); AL(gx, nX); AL(huu, nU); AL(gu, nU); AL(hvt, (size_t)N * m);
-    AL(Kg, (size_t)N * w->nu * w->nx); AL(kff, nU); AL(dl_k, nU);
+    AL(Kg, (size_t)N * w->nu * w->nx); AL(kff, nU); AL(dl_k, nU); AL(El, nH); AL(Elt, nH); AL(dEl, nH);
 #undef AL
     w->ns_k = (int *)calloc(nU, sizeof(int));
     w->Psnap = (double *)calloc((size_t)(N + 1) * w->nx * w->nx, sizeof(double)); w->pvsnap = (double *)calloc(nX, sizeof(double));
@@ -159,7 +163,7 @@ static void ws_free(ws_t *w)
                      &w->sn, &w->cs, &w->snt, &w->cst, &w->C, &w->Ct, &w->H, &w->Ht, &w->Hxx, &w->gx, &w->huu, &w->gu,
                      &w->hvt, &w->Kg, &w->kff, &w->corr, &w->dXc, &w->dUc, &w->dSc, &w->dZc, &w->lamnc};
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); i++) free(*ps[i]);
-    free(w->dl_k); free(w->ns_k); free(w->Psnap); free(w->pvsnap);
+    free(w->dl_k); free(w->ns_k); free(w->Psnap); free(w->pvsnap); free(w->El); free(w->Elt); free(w->dEl);
     free(w);
 }
 
@@ -258,16 +262,35 @@ static double eval_point(const ws_t *w, const double *xs, const double *X, const
     return f;
 }
 
-static double barrier_and_infeas(const ws_t *w, double f, const double *C, const double *H, const double *S, double mu,
-                                 double *theta)
+/* Elastic phase (round 4; the last resort where IPOPT would run its restoration phase).  The pair and obstacle rows h(x) >= 0 become
+       h(x) + t - s = 0,  s >= 0,  t >= 0,   objective + rho sum t        (rho = NMPC_ELASTIC_RHO)
+   with both s and t under the barrier; the dynamics stay equalities (any control sequence has a trajectory: only the inequality rows can make
+   the problem locally infeasible), so the Riccati structure is untouched.  Stationarity gives the row's dual z in (0, rho) and z_t = rho - z.
+   Newton step of one row with D = s/z + t/(rho - z) and q = h - mu/z + mu/(rho - z):
+       dz = -(J dx + q) / D,   ds = (mu - s z - s dz) / z,   dt = (mu - t (rho - z) + t dz) / (rho - z)
+   i.e. in the condensed stage blocks Sigma = 1/D replaces z/s and v = z - q/D replaces mu/s - Sigma (h - s) (both reduce to the plain forms
+   for t -> 0, rho -> inf).  A converged elastic solve solves the NLP iff every t has closed (<= NMPC_X0_TOL); otherwise it is a stationary
+   point of the infeasibility and is reported as NMPC_STATUS_STALLED.  Measured on the 42 captured failures / fixtures of the composite
+   (tools): 7 failed -> 0 with this phase in place of the second cold retry; closed-loop soaks 11 failed of 122,880 -> 2. */
+#define ELS(w, s) ((w)->el && (s) >= (w)->o_pr)      /* elastic slot */
+static double barrier_and_infeas_t(const ws_t *w, double f, const double *C, const double *H, const double *S, const double *Tv, double mu,
+                                   double *theta)
 {
-    double lg = 0.0, th = 0.0;
+    double lg = 0.0, th = 0.0, pen = 0.0;
     for (int i = 0; i < w->N * w->nx; i++) th += fabs(C[i]);
     for (int k = 0; k <= w->N; k++)
         for (int s = 0; s < w->nh; s++)
-            if (slot_active(w, k, s)) { size_t o = (size_t)k * w->nh + s; lg += log(S[o]); th += fabs(H[o] - S[o]); }
+            if (slot_active(w, k, s)) {
+                size_t o = (size_t)k * w->nh + s;
+                if (ELS(w, s)) { lg += log(S[o]) + log(Tv[o]); th += fabs(H[o] + Tv[o] - S[o]); pen += w->rho * Tv[o]; }
+                else { lg += log(S[o]); th += fabs(H[o] - S[o]); }
+            }
     *theta = th;
-    return f - mu * lg;
+    return f + pen - mu * lg;
+}
+static double barrier_and_infeas(const ws_t *w, double f, const double *C, const double *H, const double *S, double mu, double *theta)
+{
+    return barrier_and_infeas_t(w, f, C, H, S, w->El, mu, theta);
 }
 
 /* Cholesky of the leading n x n of a (row-major, ld), in place (lower). 0 = ok, 1 = not positive definite */
@@ -391,6 +414,12 @@ static double barrier_restart(ws_t *w, const double *xs, double mu, int cold)
             size_t o = (size_t)k * nh + s;
             if (!slot_active(w, k, s)) { w->S[o] = 1.0; w->Z[o] = 0.0; continue; }
             double floor_ = (s < w->o_xl) ? 1e-12 : bp;
+            if (ELS(w, s)) {      /* elastic row: t absorbs the violation, s = h + t >= bp, 0 < z < rho */
+                w->El[o] = fmax(bp, bp - w->H[o]);
+                w->S[o] = w->H[o] + w->El[o];
+                w->Z[o] = fmin(mu / w->S[o], 0.5 * w->rho);
+                continue;
+            }
             w->S[o] = fmax(w->H[o], floor_);
             w->Z[o] = mu / w->S[o];
         }
@@ -428,6 +457,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     }
 
     memset(w->dl_k, 0, sizeof(double) * (size_t)N * nu); memset(w->ns_k, 0, sizeof(int) * (size_t)N * nu);
+    w->el = 0;
     double mu = w->mu_init;
     double f = barrier_restart(w, xs, mu, 0);      /* push inside the simple bounds (IPOPT bound_push = bound_frac = 1e-2), slacks, duals */
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
@@ -450,7 +480,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
     int it_base = 0;      /* iteration at which the current attempt started (watchdog reference) */
 #define COLD_RETRY()                                                                                                              \
     do {                                                                                                                          \
-        n_cold++; it_base = it; mu = (n_cold == 1) ? w->mu_init : 10.0 * w->mu_init; f = barrier_restart(w, xs, mu, 1);           \
+        n_cold++; it_base = it; w->el = n_cold >= 2; mu = w->mu_init; f = barrier_restart(w, xs, mu, 1);                          \
         delta_last = 0.0; nu_pen = 1.0; need_shift = 0; mcount = 0; n_tiny = 0; n_restart = 0;                                    \
         memset(w->dl_k, 0, sizeof(double) * (size_t)N * nu); memset(w->ns_k, 0, sizeof(int) * (size_t)N * nu);                    \
     } while (0)
@@ -494,7 +524,8 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             for (int s = 0; s < nh; s++)
                 if (slot_active(w, k, s)) {
                     size_t o = (size_t)k * nh + s;
-                    e_h = fmax(e_h, fabs(w->H[o] - w->S[o]));
+                    if (ELS(w, s)) { e_h = fmax(e_h, fabs(w->H[o] + w->El[o] - w->S[o])); cmp0 = fmax(cmp0, w->El[o] * (w->rho - w->Z[o])); }
+                    else e_h = fmax(e_h, fabs(w->H[o] - w->S[o]));
                     zsum += w->Z[o];
                     cmp0 = fmax(cmp0, w->S[o] * w->Z[o]);
                 }
@@ -504,7 +535,15 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         double E0 = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cmp0 / s_c));
         kkt = E0;
         if (!(E0 == E0)) { if (n_cold < max_cold && it < w->max_iter) { COLD_RETRY(); continue; } status = NMPC_STATUS_NUMERIC; break; }
-        if (E0 <= w->tol) { status = NMPC_STATUS_CONVERGED; break; }
+        if (E0 <= w->tol) {
+            status = NMPC_STATUS_CONVERGED;
+            if (w->el) {      /* the penalty problem's solution solves the NLP only if every elastic variable has closed */
+                double tmax = 0.0;
+                for (int k = 0; k <= N; k++) for (int s = w->o_pr; s < nh; s++) if (slot_active(w, k, s)) tmax = fmax(tmax, w->El[(size_t)k * nh + s]);
+                if (tmax > NMPC_X0_TOL) status = NMPC_STATUS_STALLED;
+            }
+            break;
+        }
         if (it >= w->max_iter) { status = NMPC_STATUS_MAX_ITER; break; }
         if (n_cold < max_cold && it - it_base >= NMPC_COLD_RETRY_ITERS) { COLD_RETRY(); continue; }
         /* ---- monotone barrier update (IPOPT eq. 7) */
@@ -513,7 +552,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             double cm = 0.0;
             for (int k = 0; k <= N; k++)
                 for (int s = 0; s < nh; s++)
-                    if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; cm = fmax(cm, fabs(w->S[o] * w->Z[o] - mu)); }
+                    if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; cm = fmax(cm, fabs(w->S[o] * w->Z[o] - mu)); if (ELS(w, s)) cm = fmax(cm, fabs(w->El[o] * (w->rho - w->Z[o]) - mu)); }
             double Emu = fmax(fmax(e_d / s_d, e_c), fmax(e_h, cm / s_c));
             if (mu > mu_min && Emu <= 10.0 * mu) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
             else break;
@@ -536,7 +575,15 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                     for (int c = 0; c < nx; c++) { Hk[c * nx + c] = 2 * w->qd[c]; g[c] = 2 * w->qd[c] * (x[c] - xs[c]); }
                 /* v = mu/s - sigma (h - s) per slot; g -= Jx^T v; Hxx += Jx^T Sigma Jx - z * hess(h) */
                 double v[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];
-                for (int s = 0; s < nh; s++) v[s] = slot_active(w, k, s) ? (mu / s_[s] - z[s] / s_[s] * (h[s] - s_[s]) - w->corr[(size_t)k * nh + s]) : 0.0;
+                double sige[4 * NUM_ + 2 * NXM + 64 + NMPC_MAX_ROBOTS * NMPC_MAX_OBSTACLES];      /* Sigma per slot (elastic rows: 1 / (s/z + t/(rho-z))) */
+                for (int s = 0; s < nh; s++) {
+                    if (!slot_active(w, k, s)) { v[s] = 0.0; sige[s] = 0.0; continue; }
+                    if (ELS(w, s)) {
+                        const double t_ = w->El[(size_t)k * nh + s], D_ = s_[s] / z[s] + t_ / (w->rho - z[s]);
+                        const double q_ = h[s] - mu / z[s] + mu / (w->rho - z[s]);
+                        sige[s] = 1.0 / D_; v[s] = z[s] - q_ / D_;
+                    } else { sige[s] = z[s] / s_[s]; v[s] = mu / s_[s] - z[s] / s_[s] * (h[s] - s_[s]) - w->corr[(size_t)k * nh + s]; }
+                }
                 for (int c = 0; c < nx; c++) tmp[c] = 0.0;
                 jxT_apply(w, k, x, v, tmp);
                 for (int c = 0; c < nx; c++) g[c] -= tmp[c];
@@ -548,7 +595,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                     for (int pq = 0; pq < w->M; pq++) {
                         int i = w->pi[pq], j = w->pj[pq];
                         double dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1];
-                        double sg = z[w->o_pr + pq] / s_[w->o_pr + pq], zz = z[w->o_pr + pq];
+                        double sg = sige[w->o_pr + pq], zz = z[w->o_pr + pq];
                         double e00 = 4 * sg * dx * dx - 2 * zz, e01 = 4 * sg * dx * dy, e11 = 4 * sg * dy * dy - 2 * zz;
                         int a = 3 * i, b = 3 * j;
                         Hk[a * nx + a] += e00; Hk[a * nx + a + 1] += e01; Hk[(a + 1) * nx + a] += e01; Hk[(a + 1) * nx + a + 1] += e11;
@@ -561,7 +608,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                             double dx = x[3 * i] - w->obs[3 * o], dy = x[3 * i + 1] - w->obs[3 * o + 1];
                             double rr = sqrt(dx * dx + dy * dy), n0 = dx / rr, n1 = dy / rr;
                             int sl = w->o_ob + i * w->K + o;
-                            double sg = z[sl] / s_[sl], zz = z[sl] / rr;
+                            double sg = sige[sl], zz = z[sl] / rr;
                             int a = 3 * i;
                             Hk[a * nx + a] += sg * n0 * n0 - zz * (1 - n0 * n0);
                             Hk[a * nx + a + 1] += sg * n0 * n1 + zz * n0 * n1;
@@ -785,8 +832,20 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             for (int s = 0; s < nh; s++) {
                 size_t o = (size_t)k * nh + s;
                 if (!slot_active(w, k, s)) { w->dS[o] = 0.0; w->dZ[o] = 0.0; continue; }
-                double ds = Jd[s] + (w->H[o] - w->S[o]);
-                double dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o] - w->corr[o];
+                double ds, dz;
+                w->dEl[o] = 0.0;
+                if (ELS(w, s)) {
+                    const double zz = w->Z[o], rz = w->rho - zz, D_ = w->S[o] / zz + w->El[o] / rz, q_ = w->H[o] - mu / zz + mu / rz;
+                    dz = -(Jd[s] + q_) / D_;
+                    ds = (mu - w->S[o] * zz - w->S[o] * dz) / zz;
+                    const double dt = (mu - w->El[o] * rz + w->El[o] * dz) / rz;
+                    w->dEl[o] = dt;
+                    if (dt < 0.0) a_p = fmin(a_p, -tau * w->El[o] / dt);
+                    if (dz > 0.0) a_d = fmin(a_d, tau * rz / dz);      /* rho - z stays positive */
+                } else {
+                    ds = Jd[s] + (w->H[o] - w->S[o]);
+                    dz = (mu - w->S[o] * w->Z[o] - w->Z[o] * ds) / w->S[o] - w->corr[o];
+                }
                 w->dS[o] = ds; w->dZ[o] = dz;
                 if (s >= w->o_pr) mult_max = fmax(mult_max, fabs(w->Z[o] + dz));
                 if (ds < 0.0) a_p = fmin(a_p, -tau * w->S[o] / ds);
@@ -826,7 +885,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
             const double *x = w->X + (size_t)k * nx;
             if (k >= 1 && k < N) for (int c = 0; c < nx; c++) dphi += 2 * w->qd[c] * (x[c] - xs[c]) * w->dX[(size_t)k * nx + c];
             if (k < N) for (int c = 0; c < nu; c++) dphi += 2 * w->rd[c] * w->U[(size_t)k * nu + c] * w->dU[(size_t)k * nu + c];
-            for (int s = 0; s < nh; s++) if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; dphi -= mu * w->dS[o] / w->S[o]; }
+            for (int s = 0; s < nh; s++) if (slot_active(w, k, s)) { size_t o = (size_t)k * nh + s; dphi -= mu * w->dS[o] / w->S[o]; if (ELS(w, s)) dphi += (w->rho - mu / w->El[o]) * w->dEl[o]; }
         }
         if (th0 > 0.0) {
             /* Nocedal-Wright (18.36) with rho = 0.1.  In exact arithmetic dphi <= ||multipliers+||_inf * theta, so the
@@ -890,9 +949,9 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         for (int ls = 0; ls < 30 && !pc_taken; ls++) {
             for (size_t i = 0; i < (size_t)(N + 1) * nx; i++) w->Xt[i] = w->X[i] + alpha * w->dX[i];
             for (size_t i = 0; i < (size_t)N * nu; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
-            for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) w->St[i] = w->S[i] + alpha * w->dS[i];
+            for (size_t i = 0; i < (size_t)(N + 1) * nh; i++) { w->St[i] = w->S[i] + alpha * w->dS[i]; w->Elt[i] = w->El[i] + alpha * w->dEl[i]; }
             ft = eval_point(w, xs, w->Xt, w->Ut, w->snt, w->cst, w->Ct, w->Ht);
-            double tht, phit = barrier_and_infeas(w, ft, w->Ct, w->Ht, w->St, mu, &tht);
+            double tht, phit = barrier_and_infeas_t(w, ft, w->Ct, w->Ht, w->St, w->Elt, mu, &tht);
             if (phit + nu_pen * tht <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
             if (ls < 29) alpha *= 0.5;
         }
@@ -907,6 +966,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
         /* accept (also when the search ran out: tiny step, as IPOPT's "tiny step" rule) */
         { double *t;
           t = w->X; w->X = w->Xt; w->Xt = t; t = w->U; w->U = w->Ut; w->Ut = t; t = w->S; w->S = w->St; w->St = t;
+          if (w->el) { t = w->El; w->El = w->Elt; w->Elt = t; }
           t = w->C; w->C = w->Ct; w->Ct = t; t = w->H; w->H = w->Ht; w->Ht = t;
           t = w->sn; w->sn = w->snt; w->snt = t; t = w->cs; w->cs = w->cst; w->cst = t; }
         f = ft;
@@ -916,6 +976,7 @@ static int solve_one(ws_t *w, const double *p, const double *w0, double *wout, d
                     size_t o = (size_t)k * nh + s;
                     double z = w->Z[o] + a_d * w->dZ[o];
                     double lo = mu / (1e10 * w->S[o]), hi = 1e10 * mu / w->S[o];
+                    if (ELS(w, s)) hi = fmin(hi, w->rho - mu / (1e10 * w->El[o]));
                     w->Z[o] = fmin(fmax(z, lo), hi);
                 }
         for (size_t i = nx; i < (size_t)(N + 1) * nx; i++) w->lam[i] += alpha * (w->lamn[i] - w->lam[i]);

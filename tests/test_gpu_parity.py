@@ -351,7 +351,7 @@ def test_cold_start_retry_rescues_stalls_and_cyclers(built):
     stall_case.npz (converges to an infeasible stationary point; IPOPT would switch to restoration), cold_retry_cases.npz (the 9 of 10,240
     solves that stall, cycle until max_iter or fail numerically without the retry) and cold_retry_cases2.npz (3 of 30,720 that need the second
     retry): after three barrier restarts — or 500 iterations of an attempt without convergence — the solve restarts from the reference's own
-    cold start X_k = x0, U = 0 (C6:398-400), at most twice (the second time with mu = 10 mu_init), and converges, on every kernel, like the oracle."""
+    cold start X_k = x0, U = 0 (C6:398-400), at most twice (the second time in the elastic phase, round 4), and converges, on every kernel, like the oracle."""
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "stall_case.npz"))
     ocfg = _composite_cfg()
@@ -381,6 +381,26 @@ def test_cold_start_retry_rescues_stalls_and_cyclers(built):
             # degenerate points of the batch (robots wedged between obstacles, dependent active rows, multipliers of 1e4 and beyond), where
             # the solver's criterion — IPOPT's error SCALED by the multiplier norm — is met (kkt <= 1e-8 above) while a least-squares
             # multiplier fit with bounded iterations is not meaningful
+            assert k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
+
+
+def test_elastic_phase_rescues_the_captured_soak_failures(built):
+    """tests/golden/elastic_cases.npz (16 root failures of composite closed-loop soaks before the elastic phase existed; see the CPU test of
+    the same name): with the elastic phase as the second restart of last resort every kernel converges on all of them, like the oracle —
+    measured: the oracle's point on 15 of 16 on every kernel, identical iteration counts on 11-13 of 16."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "elastic_cases.npz"))
+    ccfg = _composite_cfg()
+    ref = O.solve_batch(O.make_config(ccfg, max_iter=2000), z["p"], z["w"])
+    assert (ref["status"] == 0).all()
+    for kernel in (None, "3", "4", "2", "1"):
+        r = _np(_solver(ccfg, len(z["p"]), max_iter=2000, kernel=kernel).solve_batch(z["p"], z["w"]))
+        same = np.max(np.abs(r["x"] - ref["x"]), axis=1) <= W_TOL
+        print(f"elastic fixtures, kernel {kernel}: converged {(r['status'] == 0).sum()} of 16, same point as the oracle {same.sum()}, identical iteration counts {(r['iters'] == ref['iters']).sum()}")
+        assert (r["status"] == 0).all() and (r["kkt"] <= 1e-8).all(), (kernel, r["status"], r["iters"])
+        assert same.sum() >= 13 and (r["iters"] == ref["iters"]).sum() >= 9, (kernel, same, r["iters"], ref["iters"])
+        for b in np.where(~same)[0][:2]:
+            k = R.kkt_report(ccfg, r["x"][b], z["p"][b], tol_active=1e-3)
             assert k["eq"] < 1e-7 and k["ineq"] < 1e-7 and k["bnd"] < 1e-9, (b, k)
 
 
