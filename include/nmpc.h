@@ -43,8 +43,9 @@ extern "C" {
 #define NMPC_STATUS_MAX_ITER 1       /* iteration limit hit; last iterate returned               */
 #define NMPC_STATUS_NUMERIC 2        /* inertia correction exhausted / non-finite step           */
 #define NMPC_STATUS_INFEASIBLE_X0 3  /* a stage-0 pair/obstacle row is violated by the pinned x0 */
-#define NMPC_STATUS_STALLED 4        /* step length < 1e-10 in 5 consecutive iterations: converging to an infeasible stationary
-                                        point (where IPOPT enters its restoration phase); last iterate returned */
+#define NMPC_STATUS_STALLED 4        /* the restarts of last resort are spent (barrier restarts, the cold start, the elastic phase — where
+                                        IPOPT runs its restoration phase) and the iteration still stalls, or the elastic phase converged with
+                                        an elastic variable open: a stationary point of the infeasibility; last iterate returned */
 
 /* return codes */
 #define NMPC_OK 0

@@ -31,7 +31,10 @@
  *           steps below 1e-10) triggers a barrier restart from the interior-pushed current
  *           point (at most 3, then NMPC_STATUS_STALLED) in place of IPOPT's restoration
  *           phase; a solve that still fails (stall after the restarts, numerical failure, 500 iterations
- *           without convergence) is restarted once from the reference's cold start X_k = x0, U = 0.
+ *           without convergence) is restarted from the reference's cold start X_k = x0, U = 0, and a
+ *           second time from there in an ELASTIC phase (pair / obstacle rows relaxed under an l1
+ *           penalty: see barrier_and_infeas_t below) — the restoration of last resort (round 4).
+ *           The backward sweep re-factors only a few stages after a rejected pivot (round 4, see the sweep).
  *           Parity is therefore at the KKT point, not on iterates.
  *   shift:  C6:160-169,460-465; plant step AllScripts/casadi_test.py:17-26.
  *
