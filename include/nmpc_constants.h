@@ -37,6 +37,15 @@
    ten times larger barrier parameter.  Measured on the captured failures of the composite: rho = 1e2 rescues 42 of 42, 1e3 41, 1e4 40. */
 #define NMPC_ELASTIC_RHO 100.0
 
+/* LIDAR solve only (round 4): watchdog of the line search, after IPOPT's (watchdog_shortened_iter_trigger = 10): once the l1-merit backtracking
+   has shortened NMPC_WATCHDOG_TRIGGER successive steps, the next step whose fraction-to-the-boundary length is at least NMPC_WATCHDOG_MIN_AP
+   is taken at that length without the merit test and the non-monotone merit history starts afresh.  The distance rows of that NLP are 1-norms
+   (V4:146-149): across their kinks the merit function rejects good steps for hundreds of iterations (the three longest solves of the bench
+   batch: 175 / 154 / 145 iterations -> 61 at most; 16,384 other instances: 374 / 319 / 271 / 231 / 155 -> 374 / 126 / 85).  IPOPT's return to
+   the stored iterate when the watchdog fails is not reproduced.  The swarm solves never meet the trigger (measured: 0 of 2048 six-robot solves). */
+#define NMPC_WATCHDOG_TRIGGER 10
+#define NMPC_WATCHDOG_MIN_AP 0.5
+
 /* Slack of the stage-0 feasibility pre-check (status 3): a measured x0 that violates a pair / obstacle row by less than this — the
    previous period's plan holds its rows to the solve tolerance only — is not reported as infeasible. */
 #define NMPC_X0_TOL 1e-6

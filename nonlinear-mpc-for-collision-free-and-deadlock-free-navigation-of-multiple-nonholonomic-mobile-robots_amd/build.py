@@ -18,6 +18,10 @@ SOURCES = ["nmpc_kernels.hip", "nmpc_solve_lds.hip", "nmpc_solve_col.hip", "nmpc
 # same pass, measured A/B in one session (round 3): two robots +2.3 %, six +3.7 % (B = 16384: +5.2 %), composite +2.3 %, ten +-0.
 FILE_FLAGS = {"nmpc_lidar.hip": os.environ.get("NMPC_LIDAR_FLAGS", "-mllvm -disable-machine-licm").split(),
               "nmpc_solve_col.hip": os.environ.get("NMPC_COL_FLAGS", "-mllvm -disable-machine-licm").split()}
+# compile units: (source, object name, extra flags).  The column-per-lane kernel is compiled in three parts (team sizes 1..5, 6..8, 9..10:
+# ~120 s each instead of ~350 s in one unit; see NMPC_COL_PART in the source); with NMPC_COL_ONLY_M (development) in one.
+UNITS = [(s, s.rsplit(".", 1)[0], []) for s in SOURCES if s != "nmpc_solve_col.hip"] \
+    + [("nmpc_solve_col.hip", "nmpc_solve_col_p%d" % k, ["-DNMPC_COL_PART=%d" % k]) for k in (1, 2, 3)]
 DEPS = SOURCES + ["nmpc_device.h", "nmpc_solve_common.h"] + [os.path.join("..", "..", "include", h) for h in ("nmpc.h", "nmpc_lidar.h", "nmpc_constants.h", "nmpc_debug.h")]
 
 
@@ -38,7 +42,8 @@ def source_hash() -> str:
             h.update(d.encode()); h.update(f.read())
     for k in ("NMPC_OPT", "NMPC_PROFILE", "NMPC_POISON", "NMPC_COL_ONLY_M", "NMPC_SHIFT_ESCALATION", "NMPC_EXTRA_DEFS"):
         h.update((k + "=" + os.environ.get(k, "")).encode())
-    h.update(repr(sorted(FILE_FLAGS.items())).encode())      # per-source code generation switches (defaults and their overrides)
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
+    h.update(repr(UNITS).encode())      # per-source code generation switches (defaults and their overrides)
     return h.hexdigest()[:16]
 
 
@@ -107,17 +112,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     skip = set(filter(None, os.environ.get("NMPC_REUSE_OBJ", "").split(",")))   # development: keep the objects of unchanged sources
 
-    def cc(src):
-        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+    units = [(s, s.rsplit(".", 1)[0], []) for s in SOURCES] if only else UNITS
+
+    def cc(unit):
+        src, name, extra = unit
+        obj = os.path.join(objdir, name + ".o")
         if src in skip and os.path.exists(obj):
             return obj
-        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
         return obj
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(cc, SOURCES))
+    # longest units first; no more compilers at once than cores
+    order = sorted(units, key=lambda u: {"nmpc_solve_col.hip": 0, "nmpc_solve_lds.hip": 1, "nmpc_kernels.hip": 2}.get(u[0], 3))
+    with ThreadPoolExecutor(max_workers=max(1, min(len(order), os.cpu_count() or 1))) as ex:
+        objs = list(ex.map(cc, order))
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs, cwd=CSRC)
     _record("compiled", time.time() - t0)
     return SO

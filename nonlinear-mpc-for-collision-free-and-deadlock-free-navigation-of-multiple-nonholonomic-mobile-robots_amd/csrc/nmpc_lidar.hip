@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     bool need_shift = false, restarting = false;
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0, mh1 = 0, mh2 = 0, mh_mu = -1, mh_nu = -1;
-    int mcount = 0;
+    int mcount = 0, n_short = 0;      // n_short: successive steps the backtracking shortened (watchdog, include/nmpc_constants.h)
 
     auto cold_retry = [&]() { cold = true; n_cold++; it_base = it; restarting = true; mu = (n_cold == 1) ? P.mu_init : 10.0 * P.mu_init; n_tiny = 0; n_restart = 0; };
     for (;;) {      // (re)start of the barrier iteration
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
         __syncthreads();
         f = eval_point(oV, oU, th0, e_c);
         __syncthreads();
-        delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false;
+        delta_last = 0.0; nu_pen = 1.0; need_shift = false; mcount = 0; restarting = false; n_short = 0;
 
         for (;;) {
             LP(0);
@@ -842,6 +842,8 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
             if (mcount > 2) mref = fmax(mref, mh2);
             mref = uni(mref);
             mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
+            const bool wd_fire = n_short >= NMPC_WATCHDOG_TRIGGER && a_p >= NMPC_WATCHDOG_MIN_AP;
+            bool wd_took = false;
             for (int ls = 0; ls < 30; ls++) {
                 double tb = 0.0;
                 LogSum lgt_;
@@ -871,13 +873,16 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
                 ft = eval_point(oVt, oUt, tht, ect);
                 const double lgt = wlogsum_(lgt_);
                 tb = wsum_(tb);
-                if ((ft - mu * lgt) + nu_pen * (tht + tb) <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
+                const double mt = (ft - mu * lgt) + nu_pen * (tht + tb);
+                if (wd_fire && isfinite(mt)) { mcount = 0; wd_took = true; break; }      // watchdog: the fraction-to-the-boundary step without the merit test
+                if (mt <= mref + 1e-4 * alpha * Dm + 1e-13 * fabs(phi0)) break;
                 if (ls < 29) alpha = uni(alpha * 0.5);
                 __syncthreads();
             }
             a_d = uni(fmin(a_d, alpha));
             LP(8);
             n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
+            n_short = (!wd_took && alpha < a_p) ? n_short + 1 : 0;
             // ---- G. accept: duals and slacks (they need the old primal point), then the primal point
             auto upd = [&](double s_, double z_, double h_, double jd_, double &sn_, double &zo_) {
                 const double ds_ = jd_ + (h_ - s_), dz_ = qdiv(mu - s_ * z_ - z_ * ds_, s_);

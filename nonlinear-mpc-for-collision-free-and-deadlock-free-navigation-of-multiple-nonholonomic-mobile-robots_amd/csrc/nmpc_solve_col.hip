@@ -1652,24 +1652,50 @@ template <int M_> static hipError_t launch3_m(const KParams &P, int B, const dou
                  : launch3_mt<M_, 0>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
 }
 
-// shape: 0 = throughput (one wavefront per instance), 1 / 2 = latency (two / four wavefronts per instance, see the kernel)
-hipError_t launch_solve_col(const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status,
-                            int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
+// The team sizes are instantiated in up to three objects so that the build spreads over the cores (one hipcc -c per part, see build.py;
+// the ten team sizes take ~350 s in one translation unit): NMPC_COL_PART 0 = everything here (variants, NMPC_COL_ONLY_M), 1 = the entry
+// points below plus 1..5 robots, 2 = 6..8 robots, 3 = 9..10 robots.
+#ifndef NMPC_COL_PART
+#define NMPC_COL_PART 0
+#endif
+#define COL_ARGS_DECL const KParams &P, int m, int B, const double *p, const double *w0, double *w_out, double *obj, int32_t *status, int32_t *iters, \
+                      double *kkt, double *ws, long long *prof, hipStream_t st, int shape
+#define COL_CASE(M) case M: return launch3_m<M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+#if NMPC_COL_PART == 2
+hipError_t launch_solve_col_part2(COL_ARGS_DECL)
 {
     switch (m) {
-#ifndef NMPC_COL_ONLY_M
-    case 1: return launch3_m<1>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 2: return launch3_m<2>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 3: return launch3_m<3>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 4: return launch3_m<4>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 5: return launch3_m<5>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 6: return launch3_m<6>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 7: return launch3_m<7>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 8: return launch3_m<8>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 9: return launch3_m<9>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
-    case 10: return launch3_m<10>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+        COL_CASE(6) COL_CASE(7) COL_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+}
+#elif NMPC_COL_PART == 3
+hipError_t launch_solve_col_part3(COL_ARGS_DECL)
+{
+    switch (m) {
+        COL_CASE(9) COL_CASE(10)
+    default: return hipErrorInvalidValue;
+    }
+}
 #else
-    case NMPC_COL_ONLY_M: return launch3_m<NMPC_COL_ONLY_M>(P, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+#if NMPC_COL_PART == 1
+hipError_t launch_solve_col_part2(COL_ARGS_DECL);
+hipError_t launch_solve_col_part3(COL_ARGS_DECL);
+#endif
+// shape: 0 = throughput (one wavefront per instance), 1 / 2 = latency (two / four wavefronts per instance, see the kernel)
+hipError_t launch_solve_col(COL_ARGS_DECL)
+{
+    switch (m) {
+#ifdef NMPC_COL_ONLY_M
+        COL_CASE(NMPC_COL_ONLY_M)
+#else
+        COL_CASE(1) COL_CASE(2) COL_CASE(3) COL_CASE(4) COL_CASE(5)
+#if NMPC_COL_PART == 1
+    case 6: case 7: case 8: return launch_solve_col_part2(P, m, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+    case 9: case 10: return launch_solve_col_part3(P, m, B, p, w0, w_out, obj, status, iters, kkt, ws, prof, st, shape);
+#else
+        COL_CASE(6) COL_CASE(7) COL_CASE(8) COL_CASE(9) COL_CASE(10)
+#endif
 #endif
     default: return hipErrorInvalidValue;
     }
@@ -1685,5 +1711,9 @@ size_t col_kernel_bytes(const KParams &P, int m, int shape)
     }
 #undef LB
 }
+
+#endif      // NMPC_COL_PART
+#undef COL_CASE
+#undef COL_ARGS_DECL
 
 }  // namespace nmpc

@@ -159,6 +159,9 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
        pose and scan, U = 0), at most twice, the second time with mu = 10 mu_init.  Of 16,384 random V4 instances one crawls for
        2074 iterations at mu_init = 0.5 and converges in 23-42 from any other initial barrier parameter. */
     int n_cold = getenv("NMPC_ORACLE_NO_COLD_RETRY") ? NMPC_COLD_RETRIES : 0, it_base = 0, cold = 0;
+    /* watchdog of the line search (include/nmpc_constants.h); NMPC_LIDAR_ORACLE_WD=<trigger> overrides the trigger for experiments and tests (0 = off) */
+    const int wd_trig = getenv("NMPC_LIDAR_ORACLE_WD") ? atoi(getenv("NMPC_LIDAR_ORACLE_WD")) : NMPC_WATCHDOG_TRIGGER; int n_short = 0;
+    const int trace = getenv("NMPC_LIDAR_ORACLE_TRACE") != NULL;      /* development: one line per iteration on stderr (single instance) */
 #define LIDAR_COLD_RETRY() do { cold = 1; n_cold++; it_base = it; restarting = 1; mu = (n_cold == 1) ? w->mu_init : 10.0 * w->mu_init; n_tiny = 0; n_restart = 0; } while (0)
     double delta_last = 0.0, nu_pen = 1.0, kkt = INFINITY;
     double mh0 = 0, mh1 = 0, mh2 = 0, mh_mu = -1, mh_nu = -1; int mcount = 0;
@@ -185,7 +188,7 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
         memset(w->lam, 0, sizeof(double) * (size_t)(N + 1) * 3);
         memset(w->eta, 0, sizeof(double) * (size_t)(N + 1) * R);
         f = eval_point(w, w->V, w->U, w->sn, w->cs, &th0, &e_c);
-        delta_last = 0.0; nu_pen = 1.0; need_shift = 0; mcount = 0; restarting = 0;
+        delta_last = 0.0; nu_pen = 1.0; need_shift = 0; mcount = 0; restarting = 0; n_short = 0;
 
         for (;;) {
             /* ---- A. optimality error (IPOPT eq. 5) */
@@ -440,6 +443,8 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
             if (mcount > 1) mref = fmax(mref, mh1);
             if (mcount > 2) mref = fmax(mref, mh2);
             mh2 = mh1; mh1 = mh0; mh0 = m0; if (mcount < 3) mcount++;
+            int wd_took = 0;
+            const int wd_fire = wd_trig > 0 && n_short >= wd_trig && a_p >= NMPC_WATCHDOG_MIN_AP;
             for (int ls = 0; ls < 30; ls++) {
                 for (size_t i = 0; i < (size_t)(N + 1) * ns; i++) w->Vt[i] = w->V[i] + alpha * w->dV[i];
                 for (int i = 0; i < 2 * Nc; i++) w->Ut[i] = w->U[i] + alpha * w->dU[i];
@@ -456,11 +461,16 @@ static int solve_one(lw_t *w, const double *p, const double *w0, double *wout, d
                     TRIAL(w->SLu[o], w->U[o] - LBU(w, o / 2, o % 2), w->dU[o], w->Ut[o] - LBU(w, o / 2, o % 2));
                     TRIAL(w->SUu[o], UBU(w, o / 2, o % 2) - w->U[o], -w->dU[o], UBU(w, o / 2, o % 2) - w->Ut[o]);
                 }
-                if ((ft - mu * lgt) + nu_pen * (tht + tb) <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
+                const double mt = (ft - mu * lgt) + nu_pen * (tht + tb);
+                if (wd_fire && isfinite(mt)) { mcount = 0; wd_took = 1; break; }      /* watchdog: the fraction-to-the-boundary step, no merit test, merit history dropped */
+                if (mt <= mref + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) break;
                 if (ls < 29) alpha *= 0.5;
             }
             a_d = fmin(a_d, alpha);
             n_tiny = (alpha < 1e-10) ? n_tiny + 1 : 0;
+            n_short = (!wd_took && alpha < a_p) ? n_short + 1 : 0;      /* a shortened step: the backtracking cut it */
+            if (trace) fprintf(stderr, "it %3d mu %.3e E0 %.3e e_d %.3e e_c %.3e delta %.3e ntry %d a_p %.3e alpha %.3e a_d %.3e f %.9g theta %.3e nu %.3e\n",
+                               it, mu, E0, e_d / s_d, e_c, delta, ntry, a_p, alpha, a_d, f, theta0, nu_pen);
             /* ---- G. accept: duals and slacks (they need the old primal point), then the primal point */
 #define UPD(s_, z_, h_, jd_)                                                                                                      \
     do {                                                                                                                          \

@@ -317,3 +317,24 @@ def test_lidar_cold_start_retry(built):
     assert it <= it_ref + 3 and 1000 <= it_ref <= 1100
     assert it < 500 or abs(it - it_ref) <= 3      # 500 = NMPC_COLD_RETRY_ITERS: past it the retry ran, and must have run like the oracle's
     assert np.max(np.abs(r["x"] - ref["x"])) <= W_TOL
+
+
+def test_lidar_line_search_watchdog(built):
+    """tests/golden/lidar_watchdog_cases.npz: the bench batch's three long solves (175 / 154 / 145 iterations without the watchdog of the
+    line search, include/nmpc_constants.h) and the five longest that remain: the kernel converges all of them to the oracle's point, in the
+    oracle's iteration count (at most 61) give or take the late forks of a chaotic solve."""
+    import os
+    import torch
+    import nmpc_amd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lidar_watchdog_cases.npz"))
+    cfg = LR.lidar_v4()
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    s = nmpc_amd.LidarSolver(_product(cfg, max_iter=2000), lbx=lbx, ubx=ubx, max_batch=len(g["p"]))
+    r = _np(s.solve_batch(g["p"], g["w0"])); torch.cuda.synchronize()
+    ref = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    print("hip", r["iters"], "oracle", ref["iters"], "without the watchdog", g["iters_without"])
+    assert (r["status"] == 0).all() and (ref["status"] == 0).all()
+    assert r["iters"].max() <= 70 and (r["iters"] == ref["iters"]).mean() >= 0.75, (r["iters"], ref["iters"])
+    assert np.max(np.abs(r["f"] - ref["f"]) / np.abs(ref["f"])) < 1e-8
+    same = r["iters"] == ref["iters"]
+    assert np.max(np.abs(r["x"][same] - ref["x"][same])) <= W_TOL

@@ -139,3 +139,23 @@ def test_cold_start_retry_rescues_the_crawling_instance(monkeypatch):
     monkeypatch.setenv("NMPC_ORACLE_NO_COLD_RETRY", "1")
     r0 = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
     assert r0["status"][0] == 1 and r0["iters"][0] == 2000, (r0["status"], r0["iters"])
+
+
+def test_line_search_watchdog_cuts_the_long_solves(monkeypatch):
+    """tests/golden/lidar_watchdog_cases.npz (gen_lidar_watchdog_cases.py): the three instances of bench.py's LIDAR batch that need 175 / 154 /
+    145 iterations without the line-search watchdog (include/nmpc_constants.h: after ten shortened steps the next step with a
+    fraction-to-the-boundary length >= 0.5 is taken without the merit test) and the five longest solves that remain with it.  With the
+    watchdog every one converges in at most 61 iterations, to the same objective as without."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lidar_watchdog_cases.npz"))
+    cfg = LR.lidar_v4()
+    lbx, ubx, _, _ = LR.bounds(cfg)
+    r = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    assert (r["status"] == 0).all() and (r["iters"] == g["iters_with"]).all() and r["iters"].max() <= 61, (r["status"], r["iters"])
+    for b in range(len(g["p"])):
+        k = LR.kkt_report(cfg, r["x"][b], g["p"][b], tol_active=1e-4)
+        assert k["stat"] < 1e-5 and k["eq"] < 1e-9 and k["bnd"] == 0.0, (b, k)
+    monkeypatch.setenv("NMPC_LIDAR_ORACLE_WD", "0")
+    r0 = O.lidar_solve_batch(cfg, g["p"], g["w0"], max_iter=2000, lbx=lbx, ubx=ubx)
+    assert (r0["status"] == 0).all() and (r0["iters"] == g["iters_without"]).all() and sorted(r0["iters"])[-3:] == [145, 154, 175], r0["iters"]
+    assert np.max(np.abs(r["f"] - r0["f"]) / np.abs(r0["f"])) < 1e-8 and np.max(np.abs(r["x"] - r0["x"])) < 1e-4, (r["f"] - r0["f"], np.max(np.abs(r["x"] - r0["x"])))

@@ -15,6 +15,6 @@ DEFS="-DNMPC_SRC_HASH=\"variant_$NAME\""
 if [ "$ONLY" != "all" ]; then DEFS="$DEFS -DNMPC_COL_ONLY_M=$ONLY"; fi
 if [ -n "$PROFILE" ]; then DEFS="$DEFS -DNMPC_PROFILE"; fi
 (cd $PKG/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $DEFS "$@" -mllvm -disable-machine-licm ${SAVE_TEMPS:+-save-temps=obj} -c $SRC -o $OBJ)
-OTHERS=$(ls $PKG/build/*.o | grep -v ${SRC%.hip}.o)
+OTHERS=$(ls $PKG/build/*.o | grep -v "/${SRC%.hip}\(_p[0-9]\)\?\.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/variants/libnmpc_$NAME.so $OBJ $OTHERS
 echo "built variants/libnmpc_$NAME.so"
