@@ -320,21 +320,33 @@ def test_row_paired_layout_emulation_matches_the_one_row_layout():
         assert err < 1e-13 and np.abs(Pk - Pk.T).max() < 1e-12, (m, err)
 
 
-def _col_kernel_asm(tmp_path, m):
-    """gfx950 assembly of the column kernel instantiated for one team size (hipcc cross-compiles here)"""
+_ASM = {}      # team size -> assembly file of this session (one hipcc run per team size, the three of the hazard test in parallel)
+
+
+def _col_kernel_asm(tmp_path, m, also=()):
+    """gfx950 assembly of the column kernel instantiated for one team size (hipcc cross-compiles here); `also`: team sizes compiled
+    alongside, in parallel, for later calls"""
     import importlib
     import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     bld = importlib.import_module("nmpc_amd.build")
     hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")) if c and os.path.exists(c)), None)
     if hipcc is None:
         pytest.skip("no hipcc")
-    d = tmp_path / ("m%d" % m)
-    d.mkdir()
     src = os.path.join(bld.CSRC, "nmpc_solve_col.hip")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="t"', "-DNMPC_COL_ONLY_M=%d" % m]
-                          + bld.FILE_FLAGS.get("nmpc_solve_col.hip", [])          # the code generation switches of the shipped build
-                          + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", str(d / "col.o"), "--save-temps=obj"], cwd=bld.CSRC)
-    return str(d / "nmpc_solve_col-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+    def cc(mm):
+        d = tempfile.mkdtemp(prefix="nmpc_asm_m%d_" % mm)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", '-DNMPC_SRC_HASH="t"', "-DNMPC_COL_ONLY_M=%d" % mm]
+                              + bld.FILE_FLAGS.get("nmpc_solve_col.hip", [])          # the code generation switches of the shipped build
+                              + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", os.path.join(d, "col.o"), "--save-temps=obj"], cwd=bld.CSRC)
+        return mm, os.path.join(d, "nmpc_solve_col-hip-amdgcn-amd-amdhsa-gfx950.s")
+    todo = [mm for mm in dict.fromkeys((m,) + tuple(also)) if mm not in _ASM]
+    if todo:
+        with ThreadPoolExecutor(max_workers=len(todo)) as ex:
+            _ASM.update(dict(ex.map(cc, todo)))
+    return _ASM[m]
 
 
 def test_hot_loops_of_the_column_kernel_hold_no_spills(built, tmp_path):
@@ -342,7 +354,7 @@ def test_hot_loops_of_the_column_kernel_hold_no_spills(built, tmp_path):
     forward sweep, the loops that contain the DPP multiply-adds — hold no scratch (spill) instruction.  A spill reload inside
     a loop that prefetches waits (vmcnt is in order) for every prefetch in flight; the property is fragile under edits anywhere
     in the kernel, so it is pinned here for the headline team size."""
-    asm = _col_kernel_asm(tmp_path, 6)
+    asm = _col_kernel_asm(tmp_path, 6, also=(2, 10))      # the hazard test below reads all three
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "asm_loops.py"), asm, "_ZN4nmpc16solve_col_kernelILi6ELi0", "--all"], text=True)
     loops = []
     for line in out.splitlines():
@@ -410,7 +422,7 @@ def test_dpp_reads_of_the_column_kernel_keep_their_wait_states(built, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import asm_hazards
     for m, least in ((2, 20), (6, 150), (10, 600)):
-        n, hz = asm_hazards.check(_col_kernel_asm(tmp_path, m), "_ZN4nmpc16solve_col_kernel")
+        n, hz = asm_hazards.check(_col_kernel_asm(tmp_path, m, also=(2, 6, 10)), "_ZN4nmpc16solve_col_kernel")
         print("m=%d: %d DPP multiply-adds, %d hazards" % (m, n, len(hz)))
         assert n >= least and not hz, (m, n, hz[:5])
 
