@@ -179,8 +179,11 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds
     double *SUU = SUL + N * NU;           // [N*NU]
 
-    double *gpack = ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
-    double *gkt = ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    // DL >= 2 (small teams, throughput shape): the stage factors — written by the backward sweep, read by the forward sweep — live in LDS as well, DL >= 3:
+    // the stage packs too; otherwise both are in the instance's workspace (HBM/L2)
+    double *const dl_end = DL ? SUU + N * NU : RED + 8;
+    double *gkt = (DL >= 2) ? dl_end : ws + inst * P.stride2 + P.oKT;       // [N][KTS]
+    double *gpack = (DL >= 3) ? dl_end + (size_t)N * G::KTS : ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
     double *TPp = ws + inst * P.stride2 + P.oELAS;     // [N1*NP]   elastic variables of the pair rows (elastic phase only; always in the workspace)
     double *TOb = TPp + N1 * NP;                       // [N1*MK]   ... of the obstacle rows
     const double rho = P.rho_el;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 #ifdef NMPC_POISON
     {   // debug build: every LDS word and the instance's HBM workspace start as NMPC_POISON, so that a read of anything this solve did not
         // write shows up as a parity failure instead of depending on what ran on the CU before
-        const int nl = (int)((DL ? SUU + N * NU : RED + 8) - sm);
+        const int nl = (int)((DL ? SUU + N * NU : RED + 8) - sm) + (DL >= 2 ? N * G::KTS : 0) + (DL >= 3 ? N1 * G::PACK : 0);
         for (int e = tid; e < nl; e += TPB) sm[e] = NMPC_POISON;
         for (size_t e = tid; e < (size_t)P.stride2; e += TPB) ws[inst * P.stride2 + e] = NMPC_POISON;
         __syncthreads();
@@ -1602,7 +1605,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 }
 
 // LDS bytes of one instance of the column-per-lane kernel
-template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool duals)
+template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool duals, int fl = 0)      // fl: 2 = + stage factors, 3 = + stage packs (see the kernel)
 {
     using G = G2<M_, THB>;
     const size_t N = P.N, N1 = P.N + 1, MK = (size_t)M_ * P.K;
@@ -1611,6 +1614,8 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool du
     d += (N1 * G::NX > rg0) ? N1 * G::NX : rg0;
     d += G::NX + 8;
     if (duals) d += 2 * N1 * G::NP + 2 * N1 * MK + 4 * N * G::NU + 2 * N1 * G::NXB;
+    if (duals && fl >= 2) d += N * G::KTS;
+    if (duals && fl >= 3) d += N1 * GC<M_, THB>::PACK;
     return d * sizeof(double);
 }
 // slacks / duals in LDS: up to four robots, when eight instances still share a CU
@@ -1621,6 +1626,27 @@ template <int M_, int THB> static size_t col_lds_bytes(const KParams &P, bool du
 #define NMPC_COL_DL_BYTES (20 * 1024)
 #endif
 template <int M_, int THB> static bool col_duals_in_lds(const KParams &P) { return M_ <= NMPC_COL_DL_MAXM && col_lds_bytes<M_, THB>(P, true) <= NMPC_COL_DL_BYTES; }
+// Stage factors in LDS too (kernel mode DL = 2; 3 = the stage packs as well): TWO robots only.  Measured A/B in one session (round 4, B = 4096 /
+// 1024 / 16384): two robots +7.5 % / +4.5 % / +5 % with the factors in LDS (18 KB per instance at N = 20: eight instances per CU instead of
+// fifteen, still faster: the forward sweep reads its rows from LDS, the backward sweep stores them there), -6 % / +3 % / -22 % with the packs
+// in LDS as well (29 KB); one robot -8 % (5 -> 7.5 KB: its launch lives on occupancy), three robots -28 % (34 KB).  Identical results.
+#ifndef NMPC_COL_FL_MINM
+#define NMPC_COL_FL_MINM 2
+#endif
+#ifndef NMPC_COL_FL_MAXM
+#define NMPC_COL_FL_MAXM 2
+#endif
+#ifndef NMPC_COL_FL_MODE
+#define NMPC_COL_FL_MODE 2
+#endif
+#ifndef NMPC_COL_FL_BYTES
+#define NMPC_COL_FL_BYTES (20 * 1024)
+#endif
+template <int M_, int THB> static int col_factor_mode(const KParams &P)
+{
+    if (M_ < NMPC_COL_FL_MINM || M_ > NMPC_COL_FL_MAXM || !col_duals_in_lds<M_, THB>(P)) return 0;
+    return col_lds_bytes<M_, THB>(P, true, NMPC_COL_FL_MODE) <= NMPC_COL_FL_BYTES ? NMPC_COL_FL_MODE : 0;
+}
 
 template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B, const double *p, const double *w0, double *w_out, double *obj,
                                                         int32_t *status, int32_t *iters, double *kkt, double *ws, long long *prof, hipStream_t st, int shape)
@@ -1631,13 +1657,15 @@ template <int M_, int THB> static hipError_t launch3_mt(const KParams &P, int B,
     constexpr int DLlat = (M_ <= 6) ? 1 : 0;
     const bool lat = shape >= 1;
     const bool dl = lat ? (DLlat != 0) : (DLmax && col_duals_in_lds<M_, THB>(P));
-    size_t lds = col_lds_bytes<M_, THB>(P, dl);
+    constexpr int FLM = (M_ >= NMPC_COL_FL_MINM && M_ <= NMPC_COL_FL_MAXM) ? NMPC_COL_FL_MODE : 1;      // instantiated only for the team sizes of the switch
+    const int fl = (!lat && dl) ? col_factor_mode<M_, THB>(P) : 0;
+    size_t lds = col_lds_bytes<M_, THB>(P, dl, fl);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // four wavefronts per instance (shape 2) are instantiated for five and six robots only: they pay where a phase has > 1000 items (eight
     // obstacles: composite B=1024 28.7 k -> 33.5 k solves/s; six robots without obstacles B=512 42.3 k -> 43.4 k) and the build time counts
     constexpr int TPB4 = (M_ == 5 || M_ == 6) ? 256 : 128;
     if (shape == 2 && TPB4 == 128) shape = 1;
-    auto kern = shape == 2 ? solve_col_kernel<M_, THB, DLlat, TPB4> : (lat ? solve_col_kernel<M_, THB, DLlat, 128> : (dl ? solve_col_kernel<M_, THB, DLmax, 64> : solve_col_kernel<M_, THB, 0, 64>));
+    auto kern = shape == 2 ? solve_col_kernel<M_, THB, DLlat, TPB4> : (lat ? solve_col_kernel<M_, THB, DLlat, 128> : (fl ? solve_col_kernel<M_, THB, DLmax * FLM, 64> : (dl ? solve_col_kernel<M_, THB, DLmax, 64> : solve_col_kernel<M_, THB, 0, 64>)));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1704,7 +1732,7 @@ hipError_t launch_solve_col(COL_ARGS_DECL)
 // LDS bytes one instance of the column-per-lane kernel needs in the given shape (0 if m is not supported)
 size_t col_kernel_bytes(const KParams &P, int m, int shape)
 {
-#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 1>(P)) : col_lds_bytes<M, 0>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 0>(P));
+#define LB(M) case M: return P.thb ? col_lds_bytes<M, 1>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 1>(P), shape == 0 ? col_factor_mode<M, 1>(P) : 0) : col_lds_bytes<M, 0>(P, shape == 1 ? (M <= 6) : col_duals_in_lds<M, 0>(P), shape == 0 ? col_factor_mode<M, 0>(P) : 0);
     switch (m) {
         LB(1) LB(2) LB(3) LB(4) LB(5) LB(6) LB(7) LB(8) LB(9) LB(10)
     default: return 0;
