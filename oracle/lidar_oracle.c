@@ -14,7 +14,8 @@
  *          (V4:161-176 builds them misaligned with the packing; that array is an input here).
  *   solve  V4:157,245 nlpsol('ipopt') — the same interior-point restatement as oracle/nmpc_oracle.c (see its header: Waechter &
  *          Biegler barrier rule, fraction to the boundary, l1-merit non-monotone search, inertia shift on the control diagonal,
- *          barrier restart), applied to this NLP.  The Newton system is solved in the reduced space of the pose: the distance
+ *          barrier restart), applied to this NLP, plus — this solve only — the line-search watchdog of include/nmpc_constants.h (after
+ *          IPOPT's watchdog_shortened_iter_trigger: the 1-norm rows make the l1 merit reject good steps).  The Newton system is solved in the reduced space of the pose: the distance
  *          states are eliminated stage by stage through their own (linearised) equality rows, d = ||p - pObs||_1, which leaves
  *          a 3-state Riccati recursion; stages k >= Nc carry the held control as two extra columns of the cost-to-go.
  *   shift  V4:258-270.
