@@ -25,7 +25,9 @@ Prints ONE JSON line on rank 0 including
   sweep        — (N = 1 only) the other north-star shapes, each with its own roofline: m=2 (B=4096 and BASELINE configs[1]'s own 1024) and
                  m=10 at N=20, B=4096; m=10 at N=30, B=512 (one GPU's shard of BASELINE configs[3]) and B=4096 (the whole batch on one GPU); the six-robot +
                  eight-obstacle composite; six robots at B=16384 (the launch outgrows its longest solve); the LIDAR-state NLP with
-                 its own flop roofline and CPU baseline.
+                 its own flop roofline and CPU baseline;
+  two_streams  — (N = 1 only) the same batch through two handles on two HIP streams, launches alternating: sustained rate when a second launch may
+                 run on the SIMDs the first one's tail leaves idle (an extra; `value` is one launch at a time).
 """
 from __future__ import annotations
 
@@ -361,6 +363,28 @@ def main():
         t_h = time.perf_counter() - t3
         out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
                                "note": "same cold batch, pageable host buffers at the boundary (H2D p, w0; D2H w, status): PCIe-inclusive, never `value`"}
+    # two launches in flight: the same cold batch solved through TWO handles (two workspaces) on two HIP streams, launches alternating.  A launch of
+    # 4096 lasts as long as its longest solve; the second stream's wavefronts run on the SIMDs the first launch's tail leaves idle.  An extra:
+    # `value` above stays one launch at a time on one stream.
+    if world == 1 and args.closed_loop > 0:
+        s2 = nmpc_amd.NmpcSolver(cfg, max_batch=B)
+        sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+        pair = [solver, s2]
+        for k in range(2):
+            with torch.cuda.stream(sts[k]):
+                pair[k].solve_batch(dP, dW0)
+        torch.cuda.synchronize()
+        n2 = 8
+        t4 = time.perf_counter()
+        res2 = []
+        for k in range(n2):
+            with torch.cuda.stream(sts[k % 2]):
+                res2.append(pair[k % 2].solve_batch(dP, dW0))
+        torch.cuda.synchronize(); t_2s = time.perf_counter() - t4
+        same = all(torch.equal(rk["iters"], r["iters"]) and torch.equal(rk["status"], r["status"]) for rk in res2)
+        out["two_streams"] = {"solves_per_s": B * n2 / t_2s, "ms_per_launch": 1e3 * t_2s / n2, "launches": n2, "same_iterations_as_value_run": bool(same),
+                              "note": "two handles on two HIP streams, launches alternating (the second launch fills the SIMDs the first one's tail leaves idle); an extra, never `value`"}
+        del s2, res2
     # north-star sweep: N_robots in {2, 6, 10}, N=20, batch 4096 (+ BASELINE configs[3] and [4]); one warm-up + two timed launches each
     do_sweep = args.sweep if args.sweep >= 0 else (1 if (world == 1 and args.workload == "six" and not args.batch) else 0)
     if world == 1 and do_sweep:
@@ -486,7 +510,7 @@ def main():
     dg = {"six_B%d" % B: [round(value), round(out["roofline"]["frac"], 4), round(out["roofline"].get("traffic_GBps") or 0)]}
     for s_ in out.get("sweep", []):
         dg["%s_B%d" % (s_["workload"].split(":")[0], s_["batch"])] = [round(s_["value"]), round(s_["roofline"]["frac"], 4), round(s_["roofline"].get("traffic_GBps") or 0), int(s_["max_iters"])]
-    for k_ in ("closed_loop", "host_buffers"):
+    for k_ in ("closed_loop", "host_buffers", "two_streams"):
         if k_ in out:
             dg[k_] = round(out[k_]["solves_per_s"])
     if "cpu_baseline" in out:

@@ -28,6 +28,10 @@ print("| shape | B | solves/s | ms per launch | iterations mean \\| max | frac o
 print("|---|---|---|---|---|---|---|---|")
 print("\n".join(rows))
 cl = d.get("closed_loop", {}); hb = d.get("host_buffers", {}); cb = d.get("cpu_baseline", {})
+ts = d.get("two_streams", {})
+if ts:
+    print("\nTwo launches in flight (two handles on two HIP streams, B=4096 each, launches alternating; an extra, never `value`): **%.0f k solves/s**, %.2f ms per launch — "
+          "the second launch runs on the SIMDs the first one's tail leaves idle." % (ts["solves_per_s"] / 1e3, ts["ms_per_launch"]))
 print("\nWarm closed loop (20 periods x 4096 swarms, one `nmpc_step_batch` per period): **%.0f k solves/s** (mean %.1f iterations per warm solve).  Host (pageable numpy) "
       "buffers at the boundary: %.0f k solves/s (PCIe-inclusive, never `value`).  CPU baseline (`oracle/nmpc_oracle.c`, %d host threads, %s): **%.1f k solves/s**.  %s" % (
           cl.get("solves_per_s", 0) / 1e3, cl.get("mean_iters_later_steps", 0), hb.get("solves_per_s", 0) / 1e3, cb.get("cores", 0), cb.get("sample", "").split(";")[0], cb.get("value", 0) / 1e3,
