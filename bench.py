@@ -173,6 +173,26 @@ def timed_solves(solver, dP, dW0, steps, warmup, barrier):
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
 
 
+def two_stream_rate(solvers, dP, dW0, ref, launches=8):
+    """the same cold batch through TWO handles (two workspaces) on two HIP streams, launches alternating: (solves/s, ms per launch, results equal
+    to `ref`).  A launch lasts as long as its longest solve; the other stream's wavefronts run on the SIMDs that tail leaves idle."""
+    import torch
+    sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k in range(2):
+        with torch.cuda.stream(sts[k]):
+            solvers[k].solve_batch(dP, dW0)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    res = []
+    for k in range(launches):
+        with torch.cuda.stream(sts[k % 2]):
+            res.append(solvers[k % 2].solve_batch(dP, dW0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    same = all(torch.equal(rk["iters"], ref["iters"]) and torch.equal(rk["status"], ref["status"]) for rk in res)
+    return dP.shape[0] * launches / dt, 1e3 * dt / launches, bool(same)
+
+
 FP64_SUSTAINED_TFLOPS = 47.7   # measured on this pool with every SIMD busy (tools/valu_probe.hip: the box clocks ~1.45 GHz under sustained fp64 load, not the 2.4 GHz of the peak)
 ROOFLINE_NOTE = ("roofline blocks: compute/latency-bound fp64 kernels with zero MFMA instructions, priced against the fp64 VECTOR peak 78.6 TFLOP/s (= the fp64 matrix "
                  "peak on MI355X); achieved = algorithmic flops iters*(F_kkt+F_asm) of SURVEY.md 8(d) / kernel time from HIP events on the launch stream; frac_sustained = "
@@ -368,23 +388,10 @@ def main():
     # `value` above stays one launch at a time on one stream.
     if world == 1 and args.closed_loop > 0:
         s2 = nmpc_amd.NmpcSolver(cfg, max_batch=B)
-        sts = [torch.cuda.Stream(), torch.cuda.Stream()]
-        pair = [solver, s2]
-        for k in range(2):
-            with torch.cuda.stream(sts[k]):
-                pair[k].solve_batch(dP, dW0)
-        torch.cuda.synchronize()
-        n2 = 8
-        t4 = time.perf_counter()
-        res2 = []
-        for k in range(n2):
-            with torch.cuda.stream(sts[k % 2]):
-                res2.append(pair[k % 2].solve_batch(dP, dW0))
-        torch.cuda.synchronize(); t_2s = time.perf_counter() - t4
-        same = all(torch.equal(rk["iters"], r["iters"]) and torch.equal(rk["status"], r["status"]) for rk in res2)
-        out["two_streams"] = {"solves_per_s": B * n2 / t_2s, "ms_per_launch": 1e3 * t_2s / n2, "launches": n2, "same_iterations_as_value_run": bool(same),
+        v2, ms2, same = two_stream_rate([solver, s2], dP, dW0, r)
+        out["two_streams"] = {"solves_per_s": v2, "ms_per_launch": ms2, "launches": 8, "same_iterations_as_value_run": same,
                               "note": "two handles on two HIP streams, launches alternating (the second launch fills the SIMDs the first one's tail leaves idle); an extra, never `value`"}
-        del s2, res2
+        del s2
     # north-star sweep: N_robots in {2, 6, 10}, N=20, batch 4096 (+ BASELINE configs[3] and [4]); one warm-up + two timed launches each
     do_sweep = args.sweep if args.sweep >= 0 else (1 if (world == 1 and args.workload == "six" and not args.batch) else 0)
     if world == 1 and do_sweep:
@@ -402,6 +409,11 @@ def main():
                                  "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
                                  "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
                                  "roofline": roofline_block(c2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
+            if B2 <= 4096:        # two launches in flight (see two_stream_rate): what a second stream recovers of this shape's tail
+                s3 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
+                v3, ms3, same3 = two_stream_rate([s2, s3], torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), r2, 4)
+                out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
+                del s3
             del s2
             torch.cuda.empty_cache()
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
@@ -441,6 +453,10 @@ def main():
                                           "hbm_frac_of_algorithmic_bytes": alg_bytes / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "frac_sustained": ach / FP64_SUSTAINED_TFLOPS,
                                           "note": "flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5); latency-bound: one wavefront per instance, serial recursions over 100 stages"}})
+        ls2 = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
+        v3, ms3, same3 = two_stream_rate([ls, ls2], torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), rl_, 4)
+        out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
+        del ls2
         # PMC traffic of the LIDAR kernel (profiles/current_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
         try:
             pdl = profile_dir("lidar", Bl)
@@ -509,14 +525,14 @@ def main():
     # sweep entry (solves/s, roofline fraction, traffic), the closed-loop and host-buffer rates, the CPU baseline and the casadi probe
     dg = {"six_B%d" % B: [round(value), round(out["roofline"]["frac"], 4), round(out["roofline"].get("traffic_GBps") or 0)]}
     for s_ in out.get("sweep", []):
-        dg["%s_B%d" % (s_["workload"].split(":")[0], s_["batch"])] = [round(s_["value"]), round(s_["roofline"]["frac"], 4), round(s_["roofline"].get("traffic_GBps") or 0), int(s_["max_iters"])]
+        dg["%s_B%d" % (s_["workload"].split(":")[0], s_["batch"])] = [round(s_["value"]), round(s_["roofline"]["frac"], 4), round(s_["roofline"].get("traffic_GBps") or 0), int(s_["max_iters"]), round(s_.get("two_streams", {}).get("solves_per_s", 0))]
     for k_ in ("closed_loop", "host_buffers", "two_streams"):
         if k_ in out:
             dg[k_] = round(out[k_]["solves_per_s"])
     if "cpu_baseline" in out:
         dg["cpu_baseline"] = [round(out["cpu_baseline"]["value"]), out["cpu_baseline"]["cores"]]
     dg["casadi"] = "not importable" if isinstance(out.get("casadi"), str) else (out.get("casadi") or "not probed")
-    dg["legend"] = "workload_batch: [solves/s, frac of 78.6 TFLOP/s fp64, HBM-side GB/s (0 = no matching profile), max iterations]"
+    dg["legend"] = "workload_batch: [solves/s, frac of 78.6 TFLOP/s fp64, HBM-side GB/s (0 = no matching profile), max iterations, solves/s with two launches in flight on two streams (0 = not measured)]"
     out["digest"] = dg
     print(json.dumps(out))
     if world > 1:
