@@ -187,6 +187,48 @@ def test_bad_dispatch_order_hint_is_harmless(built):
     assert np.array_equal(r0["x"], r2["x"])
 
 
+def test_two_handles_on_two_streams_are_independent(built):
+    """INTEGRATION.md 3 / bench.py `two_streams`: launches of two handles (two workspaces) alternating on two HIP streams run concurrently — the
+    second fills the SIMDs the first one's tail leaves idle — and return bit-identical results to the same solves one at a time, for the
+    swarm solve (throughput and latency shape) and the LIDAR solve."""
+    import torch
+    import nmpc_amd
+    from oracle import lidar_ref as LR
+    sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def check(make, Pa, Wa, Pb, Wb):
+        sa, sb = make(), make()
+        Pa, Wa, Pb, Wb = (torch.as_tensor(a, device="cuda") for a in (Pa, Wa, Pb, Wb))
+        ra, rb = _np(sa.solve_batch(Pa, Wa)), _np(sb.solve_batch(Pb, Wb))
+        torch.cuda.synchronize()
+        res = []
+        for k in range(6):
+            with torch.cuda.stream(sts[k % 2]):
+                res.append(sa.solve_batch(Pa, Wa) if k % 2 == 0 else sb.solve_batch(Pb, Wb))
+        torch.cuda.synchronize()
+        for k, rk in enumerate(res):
+            ref = ra if k % 2 == 0 else rb
+            for key in ("x", "f", "status", "iters", "kkt"):
+                assert np.array_equal(_np(rk)[key], ref[key]), (k, key)
+
+    for ocfg, B in ((R.cfg_six(20), 1024), (R.cfg_six(20), 96), (R.cfg_two(20), 512)):      # 96: latency shape (two wavefronts per instance)
+        Pa, Wa = Hh.batch(ocfg, B, 3)
+        Pb, Wb = Hh.batch(ocfg, B, 4)
+        check(lambda: _solver(ocfg, B, max_iter=2000), Pa, Wa, Pb, Wb)
+    lc = LR.LidarConfig(N=25, Nc=12, R=10, T=0.3, aligned_bounds=True)
+    lbx, ubx, _, _ = LR.bounds(lc)
+    rng = np.random.default_rng(5)
+    P, W = [], []
+    for _ in range(256):
+        pose = np.array([rng.uniform(0.0, 0.15), rng.uniform(0.0, 0.15), rng.uniform(0.4, 1.1)])
+        world = [(float(rng.uniform(0.8, 2.6)), float(rng.uniform(0.3, 2.4)), float(rng.uniform(0.15, 0.3))) for _ in range(3)]
+        scan = LR.scan_of_world(pose, world, lc.R)
+        P.append(LR.make_p(lc, pose, np.array([3.0, 2.5, 0.0]) + rng.uniform(-0.3, 0.3, 3), scan)); W.append(LR.cold_start(lc, np.concatenate([pose, scan])))
+    P = np.stack(P); W = np.stack(W)
+    from tests.test_gpu_lidar import _product
+    check(lambda: nmpc_amd.LidarSolver(_product(lc, max_iter=2000), lbx=lbx, ubx=ubx, max_batch=128), P[:128], W[:128], P[128:], W[128:])
+
+
 def test_create_rejects_bad_configs(built):
     """non-positive R, negative Q / dmin, padding rows without pair rows -> NMPC_E_ARG; m outside 1..10 -> NMPC_E_UNSUPPORTED / NMPC_E_ARG."""
     import ctypes as C
