@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include "../../include/nmpc_constants.h"      // cold-start retry and inertia constants shared with the main solver and the oracles
 #include "../../include/nmpc_lidar.h"
 
@@ -148,6 +149,24 @@ __device__ __forceinline__ double wlogsum_(LogSum a)
 #else
 #define LP(i) do { } while (0)
 #endif
+// Wave-uniform base pointer indexed by a 32-bit element index: the byte offset is formed in 32 bits and zero-extended, which the compiler addresses as
+// `global_load v, v_offset, s[base:base+1]` (scalar base + 32-bit vector offset) — with a plain `double *` every access carries a 64-bit vector address
+// (two registers and two or three address instructions each: 973 of them in this kernel).  The per-instance workspace and the bound arrays are far
+// below 4 GB.  NMPC_LIDAR_SADDR = 0 keeps plain pointers (A/B).
+#ifndef NMPC_LIDAR_SADDR
+#define NMPC_LIDAR_SADDR 1
+#endif
+template <class T> struct UPtr {
+    T *b;
+    __device__ __forceinline__ T &operator[](int i) const
+    {
+#if NMPC_LIDAR_SADDR
+        return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(b)) + (size_t)((uint32_t)i * (uint32_t)sizeof(T)));
+#else
+        return b[i];
+#endif
+    }
+};
 #define SV(off, k, c) wsb[(off) + (c) * NP1 + (k)]            // state-like arrays [3 + R][N + 1]
 #define RV(off, k, m) wsb[(off) + (m) * N + ((k) - 1)]        // per-ray arrays [R][N], stages 1..N
 #define LV(k, i) wsb[olam + (i) * N + ((k) - 1)]              // multipliers of the pose rows [3][N], stages 1..N
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     if (b >= B) return;
     const int N = P.N, Nc = P.Nc, R = R_ >= 0 ? R_ : P.R, ns = 3 + R, NP1 = N + 1;
     const double T = P.T;
-    double *wsb = ws + (size_t)b * (size_t)P.total;
+    const UPtr<double> wsb{ws + (size_t)b * (size_t)P.total};
     extern __shared__ double lsm[];
     double *SB = lsm;                              // [N+1][13]  Hxx(4) gx(3) hvt sin cos pose(3)
     double *SC = SB + (size_t)NP1 * 13;            // [Nc][16]   u(2) huu(2) gu(2) K(6) kff(2) du(2)
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const
     double *SF = SP + 2 * NMPC_LIDAR_MAX_RAYS;     // [N][12]    stage maps of the forward recursion, then the stage terms of the adjoint one
     const double *pp = p_in + (size_t)b * P.np, *wi = w0 + (size_t)b * P.nvar;
     double *wo = w_out + (size_t)b * P.nvar;
-    const double *lbS = P.lb, *ubS = P.ub, *lbu = P.lb + (size_t)NP1 * ns, *ubu = P.ub + (size_t)NP1 * ns;      // component-major, stage 0 = -+inf
+    const UPtr<const double> lbS{P.lb}, ubS{P.ub}, lbu{P.lb + (size_t)NP1 * ns}, ubu{P.ub + (size_t)NP1 * ns};      // component-major, stage 0 = -+inf
     int oV = (int)P.oV, oVt = (int)P.oVt, oU = (int)P.oU, oUt = (int)P.oUt;
     const int odV = (int)P.odV, odU = (int)P.odU, oSL = (int)P.oSL, oZL = (int)P.oZL, oSU = (int)P.oSU, oZU = (int)P.oZU, oSLu = (int)P.oSLu, oZLu = (int)P.oZLu,
               oSUu = (int)P.oSUu, oZUu = (int)P.oZUu, olam = (int)P.olam, oeta = (int)P.oeta, oetan = (int)P.oetan, oWd = (int)P.oWd, ogdv = (int)P.ogdv;

@@ -50,6 +50,9 @@ __device__ __forceinline__ double lane_read(double v, int lane)      // uniform 
 #ifndef NMPC_COL_WAVES_MID
 #define NMPC_COL_WAVES_MID 1        // occupancy the compiler is ASKED for, four to six robots (see col_min_waves)
 #endif
+#ifndef NMPC_COL_WAVES_FOUR
+#define NMPC_COL_WAVES_FOUR 2       // four robots: asked for 1 the allocator lands on 257..267 registers (one wave per SIMD) since the elastic phase went in; asked for 2 it must stay within 256
+#endif
 #ifndef NMPC_COL_WAVES_LAT
 #define NMPC_COL_WAVES_LAT 2        // five / six robots, latency shape, no heading bound: with the elastic phase's code the allocator, asked for 1, lands on 255 VGPRs + 2 AGPRs = 258 > 256, i.e. ONE wave per SIMD (warm closed loop 364 k -> 256 k solves/s); asked for 2 it must stay within 256
 #endif
@@ -78,7 +81,7 @@ constexpr bool rp_live(int i, int jj, int nc, int nu) { return i >= nc || (4 * (
 // +2.5 %, 16384 +3 %.  The one variant that lands above 256 when asked for 1 (four robots, heading bounds, slacks in the workspace: 257) keeps 2.
 constexpr int col_min_waves(int m, int thb, int dl)
 {
-    return m > 6 ? 1 : (m <= 3 ? NMPC_COL_WAVES_SMALL : ((m == 4 && thb && !dl) ? 2 : ((m >= 5 && !thb && dl) ? NMPC_COL_WAVES_LAT : NMPC_COL_WAVES_MID)));
+    return m > 6 ? 1 : (m <= 3 ? NMPC_COL_WAVES_SMALL : (m == 4 ? NMPC_COL_WAVES_FOUR : ((m >= 5 && !thb && dl) ? NMPC_COL_WAVES_LAT : NMPC_COL_WAVES_MID)));
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -103,6 +106,22 @@ __device__ __forceinline__ double lane_gather(int src4, double v)     // v of la
 {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src4, __double2loint(v)));
 }
+
+#ifndef NMPC_COL_SADDR
+#define NMPC_COL_SADDR 1
+#endif
+struct UArr {      // array of the instance's workspace (or of LDS): wave-uniform base, uniform element offset, 32-bit element index (see the kernel)
+    double *b;
+    int o;
+    __device__ __forceinline__ double &operator[](int i) const
+    {
+#if NMPC_COL_SADDR
+        return *reinterpret_cast<double *>(reinterpret_cast<char *>(b) + (size_t)((uint32_t)(o + i) * 8u));
+#else
+        return b[o + i];
+#endif
+    }
+};
 
 // Stage pack of this kernel: G2's layout with a COMPACT coefficient table.  G2 keeps three coefficients for each of the NZ columns of [B A]
 // (3 NZ doubles, most of them 0, 1 or T); here PK_CF holds the four entries per robot that depend on the iterate — T cos, T sin, -T v sin,
@@ -167,25 +186,30 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
     // slacks and duals of the inequality rows: in the instance's workspace (HBM/L2) for the larger teams, whose LDS budget of
     // 20 KB (eight instances per CU) they would break; in LDS (DL = 1) for up to four robots when they fit that budget — there the
     // stage-parallel phases are most of an iteration and their loops make one trip, i.e. one exposed memory latency each
+    // The arrays are (wave-uniform base, uniform offset) pairs indexed by a 32-bit element index: the byte offset is formed in 32 bits and zero-extended,
+    // which the compiler addresses as scalar base + 32-bit vector offset (`global_load v, v_off, s[base:base+1]`) instead of a 64-bit vector address
+    // per access (two registers and two or three address instructions each).  NMPC_COL_SADDR = 0 keeps plain pointers (A/B).
     double *gd = DL ? (RED + 8) : (ws + inst * P.stride2 + P.oDUAL);
-    double *SPp = gd;                     // [N1*NP]   pair slacks
-    double *ZPp = SPp + N1 * NP;          // [N1*NP]   pair duals
-    double *SO = ZPp + N1 * NP;           // [N1*MK]   obstacle slacks
-    double *ZO = SO + N1 * MK;            // [N1*MK]
-    double *ZUL = ZO + N1 * MK;           // [N*NU]
-    double *ZUU = ZUL + N * NU;           // [N*NU]
-    double *ZXL = ZUU + N * NU;           // [N1*NXB]
-    double *ZXU = ZXL + N1 * NXB;         // [N1*NXB]
-    double *SUL = ZXU + N1 * NXB;         // [N*NU]    explicit slacks of the simple bounds
-    double *SUU = SUL + N * NU;           // [N*NU]
+    const int oZPp = N1 * NP, oSO = oZPp + N1 * NP, oZO = oSO + N1 * MK, oZUL = oZO + N1 * MK, oZUU = oZUL + N * NU, oZXL = oZUU + N * NU, oZXU = oZXL + N1 * NXB,
+              oSUL = oZXU + N1 * NXB, oSUU = oSUL + N * NU;
+    const UArr SPp{gd, 0};                // [N1*NP]   pair slacks
+    const UArr ZPp{gd, oZPp};             // [N1*NP]   pair duals
+    const UArr SO{gd, oSO};               // [N1*MK]   obstacle slacks
+    const UArr ZO{gd, oZO};               // [N1*MK]
+    const UArr ZUL{gd, oZUL};             // [N*NU]
+    const UArr ZUU{gd, oZUU};             // [N*NU]
+    const UArr ZXL{gd, oZXL};             // [N1*NXB]
+    const UArr ZXU{gd, oZXU};             // [N1*NXB]
+    const UArr SUL{gd, oSUL};             // [N*NU]    explicit slacks of the simple bounds
+    const UArr SUU{gd, oSUU};             // [N*NU]
 
     // DL >= 2 (small teams, throughput shape): the stage factors — written by the backward sweep, read by the forward sweep — live in LDS as well, DL >= 3:
     // the stage packs too; otherwise both are in the instance's workspace (HBM/L2)
-    double *const dl_end = DL ? SUU + N * NU : RED + 8;
+    double *const dl_end = DL ? gd + oSUU + N * NU : RED + 8;
     double *gkt = (DL >= 2) ? dl_end : ws + inst * P.stride2 + P.oKT;       // [N][KTS]
     double *gpack = (DL >= 3) ? dl_end + (size_t)N * G::KTS : ws + inst * P.stride2 + P.oPACK;   // [N][PACK] + terminal [2*NX]
-    double *TPp = ws + inst * P.stride2 + P.oELAS;     // [N1*NP]   elastic variables of the pair rows (elastic phase only; always in the workspace)
-    double *TOb = TPp + N1 * NP;                       // [N1*MK]   ... of the obstacle rows
+    const UArr TPp{ws + inst * P.stride2 + P.oELAS, 0};           // [N1*NP]   elastic variables of the pair rows (elastic phase only; always in the workspace)
+    const UArr TOb{ws + inst * P.stride2 + P.oELAS, N1 * NP};     // [N1*MK]   ... of the obstacle rows
     const double rho = P.rho_el;
     double *gck = ws + inst * P.stride2 + P.oCKPT;     // [(N-1)/NMPC_CKPT_EVERY + 1][NX + 1][64]  saved cost-to-go of the backward sweep (column-per-lane registers as they are)
     const double *pp = p_in + inst * (2 * NX);
@@ -195,7 +219,7 @@ __global__ __launch_bounds__(TPBK, col_min_waves(M_, THB, DL)) void solve_col_ke
 #ifdef NMPC_POISON
     {   // debug build: every LDS word and the instance's HBM workspace start as NMPC_POISON, so that a read of anything this solve did not
         // write shows up as a parity failure instead of depending on what ran on the CU before
-        const int nl = (int)((DL ? SUU + N * NU : RED + 8) - sm) + (DL >= 2 ? N * G::KTS : 0) + (DL >= 3 ? N1 * G::PACK : 0);
+        const int nl = (int)((DL ? gd + oSUU + N * NU : RED + 8) - sm) + (DL >= 2 ? N * G::KTS : 0) + (DL >= 3 ? N1 * G::PACK : 0);
         for (int e = tid; e < nl; e += TPB) sm[e] = NMPC_POISON;
         for (size_t e = tid; e < (size_t)P.stride2; e += TPB) ws[inst * P.stride2 + e] = NMPC_POISON;
         __syncthreads();

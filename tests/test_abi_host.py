@@ -393,6 +393,52 @@ def _kernel_resources(asm_path, name_part):
     return {k: v for k, v in out.items() if "vgpr_count" in v}
 
 
+def test_throughput_kernels_keep_two_waves_per_simd(built, tmp_path):
+    """Build check on lib/libnmpc_hip.so itself (ELF notes of its gfx950 code objects): every throughput-shape instantiation of the column
+    kernel for up to six robots — what a batch of thousands runs on — fits two wavefronts per SIMD, i.e. vgpr_count <= 256 of the unified
+    512-entry file.  The four-robot kernels had slipped to 257..267 registers (one wave per SIMD: -10 % at B = 4096, -30 % at 16384)
+    when the elastic phase went in; nothing else would have noticed."""
+    import importlib
+    bld = importlib.import_module("nmpc_amd.build")
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(tools, "llvm-objcopy")) and os.path.exists(os.path.join(tools, "llvm-readelf"))):
+        pytest.skip("no llvm-objcopy / llvm-readelf")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.check_call([os.path.join(tools, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, bld.SO, str(tmp_path / "copy.so")])
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+    regs = {}
+    for n, a in enumerate(starts):
+        p = str(tmp_path / ("co%d.elf" % n))
+        with open(p, "wb") as f:
+            f.write(data[a:starts[n + 1] if n + 1 < len(starts) else len(data)])
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", p], capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:      # one block per kernel: its keys are sorted, .agpr_count comes first
+            name = re.search(r"\n\s+\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            d = {"agpr_count": int(blk.split()[0])}
+            for key in ("vgpr_count", "private_segment_fixed_size"):
+                m = re.search(r"\n\s+\.%s:\s+(\d+)" % key, blk)
+                if m:
+                    d[key] = int(m.group(1))
+            regs[name.group(1)] = d
+    col = {k: v for k, v in regs.items() if "solve_col_kernel" in k}
+    assert len(col) >= 50, len(col)
+    seen = 0
+    for k, v in col.items():
+        m = re.search(r"solve_col_kernelILi(\d+)ELi(\d)ELi(\d)ELi(\d+)E", k)
+        team, tpb = int(m.group(1)), int(m.group(4))
+        if team <= 6 and tpb == 64:
+            seen += 1
+            assert v["vgpr_count"] <= 256, (k, v)      # .vgpr_count is the unified allocation (architectural + accumulation registers)
+        if team <= 6:
+            assert v.get("private_segment_fixed_size", 0) <= 32, (k, v)      # four robots, duals in LDS: 4 spilled dwords outside the hot loops
+    assert seen >= 20, seen
+    lid = {k: v for k, v in regs.items() if "lidar_solve_kernel" in k}
+    assert len(lid) == 2 and all(v.get("private_segment_fixed_size", 0) == 0 for v in lid.values()), lid
+
+
 def test_lidar_kernel_holds_no_spills(built, tmp_path):
     """Build check: the LIDAR solve kernel (both instantiations) compiles without scratch.  Round 2's kernel reloaded spilled literals of
     log() inside its hot loops — a full vmcnt wait per reload, ~1,500 cycles per logarithm; the property depends on the

@@ -9,7 +9,11 @@ from oracle import nlp_ref as R
 from tests import helpers as Hh
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 three = R.NLPConfig(m=3, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
-cases = [("one", R.cfg_one(20)), ("three", three), ("obs3", R.cfg_obs3(20)), ("two N=60", R.cfg_two(60))]
+four = R.NLPConfig(m=4, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5)
+four_thb = R.NLPConfig(m=4, N=20, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5, th_max=2 * np.pi)
+cases = [("one", R.cfg_one(20)), ("three", three), ("obs3", R.cfg_obs3(20)), ("two N=60", R.cfg_two(60)), ("four", four), ("four thb", four_thb), ("four N=40", R.NLPConfig(m=4, N=40, T=0.3, dmin=0.4, v_max=0.15, w_max=1.5))]
+if os.environ.get("AB_CASES"):
+    cases = [c for c in cases if c[0] in os.environ["AB_CASES"].split(",")]
 for name, oc in cases:
     P, W0 = Hh.batch(oc, B, 7)
     s = nmpc_amd.NmpcSolver(Hh.to_product_cfg(oc, max_iter=2000), max_batch=B, kernel=3)
