@@ -28,5 +28,5 @@ def run(nfleet):
     print("fleets %d x %d: %.0f solves/s, %.2f ms per period, mean iterations %.2f" % (nfleet, Bf, B * periods / dt, 1e3 * dt / periods, it), flush=True)
 
 
-for n in (1, 2, 4, 1, 2):
+for n in [int(a) for a in os.environ.get("FLEETS", "1,2,4,1,2").split(",")]:
     run(n)
