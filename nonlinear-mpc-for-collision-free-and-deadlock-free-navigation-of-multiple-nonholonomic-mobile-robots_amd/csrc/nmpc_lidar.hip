@@ -139,15 +139,26 @@ __device__ __forceinline__ double wlogsum_(LogSum a)
 #define NMPC_LIDAR_UNROLL 4      // stages of the forward / adjoint recursions unrolled together: their LDS operand reads issue as one batch
 #endif
 #ifndef NMPC_LIDAR_WAVES
-#define NMPC_LIDAR_WAVES 1      // resident waves per SIMD the register budget is set for.  Measured (B = 4096 / 1024): 1 -> 63.1 k / 38.4 k solves/s, 2 -> 49.2 k / 30.0 k: with 256 registers the 5 x 5 recursion and the phases around it spill into their hot loops (every reload a full vmcnt wait), and a lone wave iterates 1.9x faster than one of a pair — which is what the longest solve of a launch sees
+#define NMPC_LIDAR_WAVES 1      // resident waves per SIMD the register budget of the default instantiation is set for (the ten-ray kernel also exists for 2: see nmpc_lidar_solve_batch).  Measured (B = 4096 / 1024): 1 -> 63.1 k / 38.4 k solves/s, 2 -> 49.2 k / 30.0 k: with 256 registers the 5 x 5 recursion and the phases around it spill into their hot loops (every reload a full vmcnt wait), and a lone wave iterates 1.9x faster than one of a pair — which is what the longest solve of a launch sees
 #endif
 #ifndef NMPC_LIDAR_CH
 #define NMPC_LIDAR_CH 5         // components of a stage whose loads are issued together
 #endif
-#ifdef NMPC_LIDAR_PROFILE      // development: cycles per phase, returned in the first entries of w_out (tools/lidar_phase_profile.py)
-#define LP(i) do { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } while (0)
+// Phase boundary: the lane index passes through an empty asm, so nothing derived from it (the per-array element indices of a phase) can be hoisted out of the
+// phase or out of the interior-point loop.  The compiler otherwise computes those indices once per solve, keeps ~100 of them live across the whole
+// iteration and — inside a 256-register budget — spills them, reloading each at its use behind a full vmcnt wait.  NMPC_LIDAR_RELANE = 0 switches it off (A/B).
+#ifndef NMPC_LIDAR_RELANE
+#define NMPC_LIDAR_RELANE 1
+#endif
+#if NMPC_LIDAR_RELANE
+#define RELANE() asm volatile("" : "+v"(lane))
 #else
-#define LP(i) do { } while (0)
+#define RELANE() do { } while (0)
+#endif
+#ifdef NMPC_LIDAR_PROFILE      // development: cycles per phase, returned in the first entries of w_out (tools/lidar_phase_profile.py)
+#define LP(i) do { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; RELANE(); } while (0)
+#else
+#define LP(i) RELANE()
 #endif
 // Wave-uniform base pointer indexed by a 32-bit element index: the byte offset is formed in 32 bits and zero-extended, which the compiler addresses as
 // `global_load v, v_offset, s[base:base+1]` (scalar base + 32-bit vector offset) — with a plain `double *` every access carries a 64-bit vector address
@@ -172,13 +183,14 @@ template <class T> struct UPtr {
 #define LV(k, i) wsb[olam + (i) * N + ((k) - 1)]              // multipliers of the pose rows [3][N], stages 1..N
 // R_ >= 0: ray count known at compile time (10 in V3 / V4); R_ = -1: run-time count up to NMPC_LIDAR_MAX_RAYS (loops unrolled to the
 // maximum, the surplus predicated off with its loads clamped to a valid component)
-template <int R_>
-__global__ __launch_bounds__(64, NMPC_LIDAR_WAVES) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
+template <int R_, int W_ = NMPC_LIDAR_WAVES>      // W_: resident waves per SIMD the register budget is set for (1: 512 registers, 2: 256)
+__global__ __launch_bounds__(64, W_) void lidar_solve_kernel(const LParams P, int B, const double *__restrict__ p_in, const double *__restrict__ w0,
                                                           double *__restrict__ w_out, double *__restrict__ obj_out, int32_t *__restrict__ status_out,
                                                           int32_t *__restrict__ iters_out, double *__restrict__ kkt_out, double *__restrict__ ws)
 {
     constexpr int RM = R_ >= 0 ? R_ : NMPC_LIDAR_MAX_RAYS, CM = 3 + RM, CH = NMPC_LIDAR_CH;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x;
+    int lane = threadIdx.x;      // re-read through RELANE() at every phase boundary
     if (b >= B) return;
     const int N = P.N, Nc = P.Nc, R = R_ >= 0 ? R_ : P.R, ns = 3 + R, NP1 = N + 1;
     const double T = P.T;
@@ -1074,6 +1086,7 @@ struct nmpc_lidar_handle {
     int32_t max_batch;
     size_t lds_bytes;           // dynamic LDS of the solve kernel: per-stage operands of the three recursions
     int device;
+    int n_cu;                   // compute units of the device (256 on MI355X): batches beyond one instance per SIMD run the two-waves-per-SIMD instantiation
     double *ws, *lb, *ub;
     int64_t ws_bytes;
 };
@@ -1098,6 +1111,7 @@ int32_t nmpc_lidar_create(const nmpc_lidar_config_t *cfg, const double *lbx, con
     nmpc_lidar_handle *h = (nmpc_lidar_handle *)calloc(1, sizeof(nmpc_lidar_handle));
     if (!h) return NMPC_E_NOMEM;
     if (hipGetDevice(&h->device) != hipSuccess) { free(h); return NMPC_E_HIP; }
+    { hipDeviceProp_t prop; h->n_cu = (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
     h->cfg = *cfg; h->max_batch = max_batch;
     h->lds_bytes = sizeof(double) * ((size_t)(N + 1) * 13 + (size_t)Nc * 16 + (size_t)(N + 1) * 3 + 2 * NMPC_LIDAR_MAX_RAYS + (size_t)N * 12);
     if (h->lds_bytes > 160 * 1024) { free(h); return NMPC_E_ARG; }       // horizon beyond the LDS of a CU: 8 (16 (N + 1) + 16 Nc + 12 N + 32) bytes <= 160 KB, i.e. N <= ~560 with Nc = N / 2
@@ -1172,7 +1186,12 @@ int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *
     // the ray count of the scripts gets its own instantiation (component loops unrolled, loads of a stage issued together); any other count
     // runs the predicated one.  The dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a handle: set per launch when this
     // handle needs more than HIP's default of 64 KB (a second handle with another horizon would otherwise change the limit under this one)
-    auto kern = (h->cfg.R == 10) ? nmpc_lidar::lidar_solve_kernel<10> : nmpc_lidar::lidar_solve_kernel<-1>;
+    // Two register budgets of the ten-ray kernel: one wave per SIMD (no spill; a lone wave iterates fastest: batches that fit the machine, whose
+    // launch is its longest solve) and two (256 registers, 68 spilled dwords outside the recursions: 5 instead of 4 instances per CU by LDS —
+    // batches beyond one instance per SIMD, whose launch is the batch's work).  Measured (round 4, V4, mean of three): B = 4096 192 k -> 199 k
+    // solves/s with the second, B = 1024 115 k -> 109 k.
+    const bool crowded = B > 4 * h->n_cu;
+    auto kern = (h->cfg.R == 10) ? (crowded ? nmpc_lidar::lidar_solve_kernel<10, 2> : nmpc_lidar::lidar_solve_kernel<10, 1>) : nmpc_lidar::lidar_solve_kernel<-1, 1>;
     if (h->lds_bytes > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) return NMPC_E_HIP;
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), h->lds_bytes, (hipStream_t)stream, h->P, B, p, w0, w_out, obj, status, iters, kkt, h->ws);
     return hipGetLastError() == hipSuccess ? NMPC_OK : NMPC_E_HIP;

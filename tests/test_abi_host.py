@@ -436,7 +436,8 @@ def test_throughput_kernels_keep_two_waves_per_simd(built, tmp_path):
             assert v.get("private_segment_fixed_size", 0) <= 32, (k, v)      # four robots, duals in LDS: 4 spilled dwords outside the hot loops
     assert seen >= 20, seen
     lid = {k: v for k, v in regs.items() if "lidar_solve_kernel" in k}
-    assert len(lid) == 2 and all(v.get("private_segment_fixed_size", 0) == 0 for v in lid.values()), lid
+    assert len(lid) == 3 and all(v.get("private_segment_fixed_size", 0) == 0 for k, v in lid.items() if "ILi10ELi2E" not in k), lid
+    assert all(v["vgpr_count"] <= 256 for k, v in lid.items() if "ILi10ELi2E" in k), lid
 
 
 def test_lidar_kernel_holds_no_spills(built, tmp_path):
@@ -453,9 +454,12 @@ def test_lidar_kernel_holds_no_spills(built, tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S"] + bld.FILE_FLAGS.get("nmpc_lidar.hip", [])
                           + [os.path.join(bld.CSRC, "nmpc_lidar.hip"), "-o", str(out)], cwd=bld.CSRC)
     kernels = _kernel_resources(str(out), "lidar_solve_kernel")
-    assert len(kernels) == 2, kernels          # ray count of the scripts (10) and the run-time count
+    assert len(kernels) == 3, kernels          # ray count of the scripts (10) at one and at two waves per SIMD, and the run-time count
     for name, res in kernels.items():
-        assert res["private_segment_fixed_size"] == 0 and res["vgpr_spill_count"] == 0, (name, res)
+        if "ILi10ELi2E" in name:               # the 256-register instantiation for batches beyond one instance per SIMD: spills outside the recursions, by choice
+            assert res["vgpr_count"] <= 256 and res["private_segment_fixed_size"] <= 320, (name, res)
+        else:
+            assert res["private_segment_fixed_size"] == 0 and res["vgpr_spill_count"] == 0, (name, res)
     text = open(out).read()
     assert text.count("v_fmac_f64_dpp") >= 40          # the column-per-lane Riccati stage is what got compiled (NMPC_LIDAR_DPP=1)
 
