@@ -55,6 +55,9 @@ int32_t nmpc_lidar_destroy(nmpc_lidar_handle_t *h);
  * Replaces sol = solver(x0=,p=,...) (V4:245) for B robots.
  *   p [B][6+2R] = [x0; xs; scan; ray angles] (V4:230-236),  w0 / w_out [B][n_var] = [vec(X); vec(U)] (V4:239-241,247-252)
  *   obj, status, iters, kkt [B]  (may be NULL)
+ * One wavefront per robot.  Batches up to one robot per SIMD (4 x the device's compute units) run the one-wave-per-SIMD build of the kernel (a lone
+ * wave iterates fastest: the launch is its longest solve), larger ones the two-waves-per-SIMD build (the launch is the batch's work).  Results do not
+ * depend on the choice.  Stream-ordered; a handle owns one workspace (two launches in flight need two handles).
  */
 int32_t nmpc_lidar_solve_batch(nmpc_lidar_handle_t *h, int32_t B, const double *p, const double *w0, double *w_out, double *obj,
                                int32_t *status, int32_t *iters, double *kkt, void *stream);
