@@ -257,3 +257,49 @@ def nlpsol(name: str, plugin: str, problem, opts: Optional[dict] = None, max_bat
     elif "acceptable_tol" in ip: cfg.tol = float(ip["acceptable_tol"])
     if "mu_init" in ip: cfg.mu_init = float(ip["mu_init"])
     return NmpcSolver(cfg, max_batch=max_batch)
+
+
+class PipelinedSolver:
+    """Several launches in flight: `depth` handles (one workspace each) on `depth` HIP streams, used round-robin.  A launch lasts as long as its longest
+    solve, so towards its end most of the device idles; the next batch's launch on another stream fills it (bench.py `two_streams`: six
+    robots, B = 4096, 277 k -> 445 k solves/s with identical results).  Not part of the reference's call surface: a host-side convenience over the
+    stream-ordered C ABI.
+
+        pipe = PipelinedSolver(cfg, max_batch=4096)
+        pending = [pipe.solve_batch(p_k, w0_k) for p_k, w0_k in batches]      # returns at once; results are ordered on the slot's stream
+        pipe.synchronize()                                                    # or: r["event"].synchronize() for one result
+    """
+
+    def __init__(self, cfg: ProblemConfig, max_batch: int = 1, depth: int = 2, **kw):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.solvers = [NmpcSolver(cfg, max_batch=max_batch, **kw) for _ in range(depth)]
+        self.torch = self.solvers[0].torch
+        self.device = self.solvers[0].device
+        with self.torch.cuda.device(self.device):
+            self.streams = [self.torch.cuda.Stream() for _ in range(depth)]
+        self._next = 0
+
+    def solve_batch(self, p, w0, **kw):
+        """NmpcSolver.solve_batch on the next slot's stream.  The slot's stream first waits for the caller's current stream (the inputs may still be in
+        production there); the result carries `event`, recorded on the slot's stream after the solve — wait on it (or call synchronize()) before reading."""
+        torch = self.torch
+        k = self._next
+        self._next = (k + 1) % len(self.solvers)
+        st = self.streams[k]
+        sol = self.solvers[k]
+        p = sol._dev(p, (-1, sol.n_p))                       # on the caller's stream (a host array is copied there)
+        w0 = sol._dev(w0, (p.shape[0], sol.n_var))
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        p.record_stream(st); w0.record_stream(st)            # the caller may drop its references at once: the allocator must not hand the inputs out again before the solve has read them
+        with torch.cuda.stream(st):
+            r = sol.solve_batch(p, w0, **kw)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        r["event"] = ev
+        r["slot"] = k
+        return r
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()

@@ -215,6 +215,19 @@ def test_two_handles_on_two_streams_are_independent(built):
         Pa, Wa = Hh.batch(ocfg, B, 3)
         Pb, Wb = Hh.batch(ocfg, B, 4)
         check(lambda: _solver(ocfg, B, max_iter=2000), Pa, Wa, Pb, Wb)
+    # the host-side convenience over the same pattern: nmpc_amd.PipelinedSolver
+    ocfg = R.cfg_six(20)
+    batches = [Hh.batch(ocfg, 256, 10 + k) for k in range(5)]
+    serial = _solver(ocfg, 256, max_iter=2000)
+    want = [_np(serial.solve_batch(Pk, Wk)) for Pk, Wk in batches]
+    pipe = nmpc_amd.PipelinedSolver(Hh.to_product_cfg(ocfg, max_iter=2000), max_batch=256, depth=2)
+    got = [pipe.solve_batch(torch.as_tensor(Pk, device="cuda"), torch.as_tensor(Wk, device="cuda")) for Pk, Wk in batches]
+    assert [g["slot"] for g in got] == [0, 1, 0, 1, 0]
+    pipe.synchronize()
+    for g, w in zip(got, want):
+        assert g["event"].query()
+        for key in ("x", "f", "status", "iters", "kkt"):
+            assert np.array_equal(g[key].cpu().numpy(), w[key]), key
     lc = LR.LidarConfig(N=25, Nc=12, R=10, T=0.3, aligned_bounds=True)
     lbx, ubx, _, _ = LR.bounds(lc)
     rng = np.random.default_rng(5)
