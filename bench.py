@@ -360,194 +360,212 @@ def main():
     # and the same cold solve with HOST buffers at the boundary (H2D of p, w0 and D2H of w included).  Both are extras:
     # `value` above is the device-resident cold solve.
     if world == 1 and args.closed_loop > 0:
-        nx = cfg.nx
-        Pc, Wc = dP.clone(), dW0.clone()
-        its, conv = [], []
-        # nmpc_step_batch: solve + shift + plant step + the next period's dispatch order (longest solves first), all on the device;
-        # the host only enqueues one call per period
-        order = torch.arange(B, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        for _ in range(args.closed_loop):
-            rr = solver.step_batch(Pc, Wc, order)
-            its.append(rr["iters"]); conv.append(rr["status"])
-        torch.cuda.synchronize(); t_cl = time.perf_counter() - t2
-        its = torch.stack(its).double().cpu().numpy(); conv = torch.stack(conv).cpu().numpy()
-        out["closed_loop"] = {"steps": args.closed_loop, "solves_per_s": B * args.closed_loop / t_cl, "ms_per_step": 1e3 * t_cl / args.closed_loop,
-                              "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
-                              "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
-                              "converged_frac": float((conv == 0).mean()),
-                              "note": "warm receding horizon, one nmpc_step_batch per period (solve in longest-first order, shift, plant step, next order: all on the device)"}
-        # the same closed loop as FOUR independent fleets of B/4 swarms, one handle and one HIP stream each: a period of one fleet overlaps the tails of the
-        # others.  The runtime maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and streams that share a queue serialise: which
-        # four streams run concurrently is the runtime's choice (measured: the first four streams of the pool 280-300 k, the next four 430-440 k), so two
-        # sets of four are timed and both rates reported
-        nfl = 4
-        Bf = B // nfl
-        fsol = [nmpc_amd.NmpcSolver(cfg, max_batch=Bf) for _ in range(nfl)]
-        pool = [torch.cuda.Stream() for _ in range(2 * nfl)]
-        rates, fmean = [], 0.0
-        for fst in (pool[:nfl], pool[nfl:]):
-            fP = [dP[f * Bf:(f + 1) * Bf].clone() for f in range(nfl)]; fW = [dW0[f * Bf:(f + 1) * Bf].clone() for f in range(nfl)]
-            ford = [torch.arange(Bf, dtype=torch.int32, device="cuda") for _ in range(nfl)]
-            for f in range(nfl):          # one untimed period per fleet: first launch of this kernel shape on this stream
-                with torch.cuda.stream(fst[f]):
-                    fsol[f].step_batch(fP[f].clone(), fW[f].clone(), ford[f].clone())
-            fits = []
+        try:
+            nx = cfg.nx
+            Pc, Wc = dP.clone(), dW0.clone()
+            its, conv = [], []
+            # nmpc_step_batch: solve + shift + plant step + the next period's dispatch order (longest solves first), all on the device;
+            # the host only enqueues one call per period
+            order = torch.arange(B, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize(); t2 = time.perf_counter()
             for _ in range(args.closed_loop):
-                for f in range(nfl):
+                rr = solver.step_batch(Pc, Wc, order)
+                its.append(rr["iters"]); conv.append(rr["status"])
+            torch.cuda.synchronize(); t_cl = time.perf_counter() - t2
+            its = torch.stack(its).double().cpu().numpy(); conv = torch.stack(conv).cpu().numpy()
+            out["closed_loop"] = {"steps": args.closed_loop, "solves_per_s": B * args.closed_loop / t_cl, "ms_per_step": 1e3 * t_cl / args.closed_loop,
+                                  "mean_iters_first_step": float(its[0].mean()), "mean_iters_later_steps": float(its[1:].mean()) if args.closed_loop > 1 else None,
+                                  "max_iters_later_steps": float(its[1:].max()) if args.closed_loop > 1 else None,
+                                  "converged_frac": float((conv == 0).mean()),
+                                  "note": "warm receding horizon, one nmpc_step_batch per period (solve in longest-first order, shift, plant step, next order: all on the device)"}
+            # the same closed loop as FOUR independent fleets of B/4 swarms, one handle and one HIP stream each: a period of one fleet overlaps the tails of the
+            # others.  The runtime maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and streams that share a queue serialise: which
+            # four streams run concurrently is the runtime's choice (measured: the first four streams of the pool 280-300 k, the next four 430-440 k), so two
+            # sets of four are timed and both rates reported
+            nfl = 4
+            Bf = B // nfl
+            fsol = [nmpc_amd.NmpcSolver(cfg, max_batch=Bf) for _ in range(nfl)]
+            pool = [torch.cuda.Stream() for _ in range(2 * nfl)]
+            rates, fmean = [], 0.0
+            for fst in (pool[:nfl], pool[nfl:]):
+                fP = [dP[f * Bf:(f + 1) * Bf].clone() for f in range(nfl)]; fW = [dW0[f * Bf:(f + 1) * Bf].clone() for f in range(nfl)]
+                ford = [torch.arange(Bf, dtype=torch.int32, device="cuda") for _ in range(nfl)]
+                for f in range(nfl):          # one untimed period per fleet: first launch of this kernel shape on this stream
                     with torch.cuda.stream(fst[f]):
-                        fits.append(fsol[f].step_batch(fP[f], fW[f], ford[f])["iters"])
-            torch.cuda.synchronize(); rates.append(Bf * nfl * args.closed_loop / (time.perf_counter() - t2))
-            fmean = float(torch.stack([i.double().mean() for i in fits]).mean().item())
-        out["closed_loop"]["four_fleets"] = {"solves_per_s": max(rates), "solves_per_s_by_stream_set": rates, "ms_per_period": 1e3 * Bf * nfl / max(rates), "mean_iters": fmean,
-                                             "note": "the same swarms as four fleets of %d, one handle and one HIP stream each; two sets of four streams timed (streams that the runtime maps "
-                                                     "to one hardware queue serialise), the better one reported" % Bf}
-        del fsol, fP, fW, fits
-        torch.cuda.synchronize(); t3 = time.perf_counter()
-        rh = solver.solve_batch(P, W0)
-        xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()
-        t_h = time.perf_counter() - t3
-        out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
-                               "note": "same cold batch, pageable host buffers at the boundary (H2D p, w0; D2H w, status): PCIe-inclusive, never `value`"}
+                        fsol[f].step_batch(fP[f].clone(), fW[f].clone(), ford[f].clone())
+                fits = []
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                for _ in range(args.closed_loop):
+                    for f in range(nfl):
+                        with torch.cuda.stream(fst[f]):
+                            fits.append(fsol[f].step_batch(fP[f], fW[f], ford[f])["iters"])
+                torch.cuda.synchronize(); rates.append(Bf * nfl * args.closed_loop / (time.perf_counter() - t2))
+                fmean = float(torch.stack([i.double().mean() for i in fits]).mean().item())
+            out["closed_loop"]["four_fleets"] = {"solves_per_s": max(rates), "solves_per_s_by_stream_set": rates, "ms_per_period": 1e3 * Bf * nfl / max(rates), "mean_iters": fmean,
+                                                 "note": "the same swarms as four fleets of %d, one handle and one HIP stream each; two sets of four streams timed (streams that the runtime maps "
+                                                         "to one hardware queue serialise), the better one reported" % Bf}
+            del fsol, fP, fW, fits
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            rh = solver.solve_batch(P, W0)
+            xh = rh["x"].cpu().numpy(); _ = rh["status"].cpu().numpy()
+            t_h = time.perf_counter() - t3
+            out["host_buffers"] = {"solves_per_s": B / t_h, "ms_per_step": 1e3 * t_h,
+                                   "note": "same cold batch, pageable host buffers at the boundary (H2D p, w0; D2H w, status): PCIe-inclusive, never `value`"}
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("closed_loop: %r" % (e_,))
     # two launches in flight: the same cold batch solved through TWO handles (two workspaces) on two HIP streams, launches alternating.  A launch of
     # 4096 lasts as long as its longest solve; the second stream's wavefronts run on the SIMDs the first launch's tail leaves idle.  An extra:
     # `value` above stays one launch at a time on one stream.
     if world == 1 and args.closed_loop > 0:
-        s2 = nmpc_amd.NmpcSolver(cfg, max_batch=B)
-        v2, ms2, same = two_stream_rate([solver, s2], dP, dW0, r)
-        out["two_streams"] = {"solves_per_s": v2, "ms_per_launch": ms2, "launches": 8, "same_iterations_as_value_run": same,
-                              "note": "two handles on two HIP streams, launches alternating (the second launch fills the SIMDs the first one's tail leaves idle); an extra, never `value`"}
-        del s2
+        try:
+            s2 = nmpc_amd.NmpcSolver(cfg, max_batch=B)
+            v2, ms2, same = two_stream_rate([solver, s2], dP, dW0, r)
+            out["two_streams"] = {"solves_per_s": v2, "ms_per_launch": ms2, "launches": 8, "same_iterations_as_value_run": same,
+                                  "note": "two handles on two HIP streams, launches alternating (the second launch fills the SIMDs the first one's tail leaves idle); an extra, never `value`"}
+            del s2
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("closed_loop: %r" % (e_,))
     # north-star sweep: N_robots in {2, 6, 10}, N=20, batch 4096 (+ BASELINE configs[3] and [4]); one warm-up + two timed launches each
     do_sweep = args.sweep if args.sweep >= 0 else (1 if (world == 1 and args.workload == "six" and not args.batch) else 0)
     if world == 1 and do_sweep:
-        del solver
-        out["sweep"] = []
-        # (workload, batch; 0 = the workload's own): the four north-star shapes, then ten robots at N=30 with the whole BASELINE batch on one
-        # GPU (what strong sharding to 512 per GPU is compared with) and six robots at B=16384, where the launch outgrows its longest solve
-        for name, bsz in (("two", 0), ("two", 1024), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):      # ("two", 1024): BASELINE configs[1]'s own batch
-            c2, B2, P2, W2 = make_batch(name, 0, bsz, max_iter=args.max_iter)
-            s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
-            d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)
-            it2 = r2["iters"].cpu().numpy(); st2 = r2["status"].cpu().numpy()
-            out["sweep"].append({"workload": "%s: m=%d, N=%d, K=%d, batch=%d, cold" % (name, c2.m, c2.N, len(c2.obstacles), B2),
-                                 "m": c2.m, "N": c2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
-                                 "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
-                                 "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
-                                 "roofline": roofline_block(c2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
-            if B2 <= 4096:        # two launches in flight (see two_stream_rate): what a second stream recovers of this shape's tail
-                s3 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
-                v3, ms3, same3 = two_stream_rate([s2, s3], torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), r2, 4)
-                out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
-                del s3
-            del s2
-            torch.cuda.empty_cache()
+        try:
+            del solver
+            out["sweep"] = []
+            # (workload, batch; 0 = the workload's own): the four north-star shapes, then ten robots at N=30 with the whole BASELINE batch on one
+            # GPU (what strong sharding to 512 per GPU is compared with) and six robots at B=16384, where the launch outgrows its longest solve
+            for name, bsz in (("two", 0), ("two", 1024), ("ten20", 0), ("ten", 0), ("composite", 0), ("ten", 4096), ("six", 16384)):      # ("two", 1024): BASELINE configs[1]'s own batch
+                c2, B2, P2, W2 = make_batch(name, 0, bsz, max_iter=args.max_iter)
+                s2 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
+                d2, k2, r2 = timed_solves(s2, torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), 2, 1, barrier)
+                it2 = r2["iters"].cpu().numpy(); st2 = r2["status"].cpu().numpy()
+                out["sweep"].append({"workload": "%s: m=%d, N=%d, K=%d, batch=%d, cold" % (name, c2.m, c2.N, len(c2.obstacles), B2),
+                                     "m": c2.m, "N": c2.N, "batch": B2, "value": B2 * 2 / d2, "unit": "solves/s", "ms_per_step": 1e3 * d2 / 2,
+                                     "mean_iters": float(it2.mean()), "max_iters": float(it2.max()), "converged_frac": float((st2 == 0).mean()),
+                                     "status_counts": {str(k): int((st2 == k).sum()) for k in np.unique(st2)},
+                                     "roofline": roofline_block(c2, B2, float(it2.sum()), k2, lib_version, int(s2.kernel_for_batch(B2)), name)})
+                if B2 <= 4096:        # two launches in flight (see two_stream_rate): what a second stream recovers of this shape's tail
+                    s3 = nmpc_amd.NmpcSolver(c2, max_batch=B2)
+                    v3, ms3, same3 = two_stream_rate([s2, s3], torch.as_tensor(P2, device="cuda"), torch.as_tensor(W2, device="cuda"), r2, 4)
+                    out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
+                    del s3
+                del s2
+                torch.cuda.empty_cache()
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("sweep: %r" % (e_,))
     # LIDAR-ray distance-state NMPC (the file BASELINE configs[4] names, AllScripts/obs_avoid_static_first_scenario_v4.py: one robot,
     # 13 states, N=100, Nc=50; SURVEY.md 0 mismatch 2): one wavefront per instance, the instance's workspace lives in HBM/L2
     if world == 1 and do_sweep:
-        lc = nmpc_amd.lidar_v4()
-        Bl = 4096
-        rngl = np.random.Generator(np.random.PCG64(SEED0 + 5))
-        poses, worlds, goals = [], [], []
-        for _ in range(Bl):
-            poses.append([rngl.uniform(0.0, 0.15), rngl.uniform(0.0, 0.15), rngl.uniform(0.4, 1.1)])
-            worlds.append([(float(rngl.uniform(0.8, 2.6)), float(rngl.uniform(0.3, 2.4)), float(rngl.uniform(0.15, 0.3))) for _ in range(3)])
-            goals.append(np.array([3.0, 2.5, 0.0]) + rngl.uniform(-0.3, 0.3, 3))
-        poses = np.array(poses); worlds = np.array(worlds)
-        lbx, ubx = lc.bounds()[:2]
-        ls = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
-        scans = ls.scan_batch(poses, worlds).cpu().numpy()          # the synthetic LaserScan of V4:29-36, on the device (nmpc_lidar_scan_batch)
-        Pl = np.stack([nmpc_amd.lidar_params(lc, poses[b], goals[b], scans[b]) for b in range(Bl)])
-        Wl = np.stack([nmpc_amd.lidar_cold_start(lc, np.concatenate([poses[b], scans[b]])) for b in range(Bl)])
-        dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
-        itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
-        alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
-        # Algorithmic flops per interior-point iteration of the LIDAR-state NLP, the same dense-Riccati count as SURVEY.md
-        # 8(d) applied to what the kernel factors: the 3-state / 2-control pose recursion (the R distance states of a stage are eliminated
-        # through their own linearised rows): F_ric = N (7/3 3^3 + 4 3^2 2 + 2 3 2^2 + 2^3/3); folding the distance rows into the pose block
-        # and recovering their steps: F_fold = N R (2 (3 3 + 3) + 2 3); evaluation / assembly: F_asm = N (22 + 14 R)
-        fl_iter_l = lc.N * ((7.0 / 3.0) * 27 + 4 * 9 * 2 + 2 * 3 * 4 + 8.0 / 3.0) + lc.N * lc.R * 30.0 + lc.N * (22.0 + 14.0 * lc.R)
-        ach = fl_iter_l * float(itl.sum()) / (kl * 1e-3) / 1e12
-        out["sweep"].append({"workload": "lidar_v4: 1 robot, 13 states (pose + 10 ray distances), N=100, Nc=50, batch=%d, cold start" % Bl,
-                             "m": 1, "N": lc.N, "batch": Bl, "value": Bl * 2 / dl, "unit": "solves/s", "ms_per_step": 1e3 * dl / 2,
-                             "mean_iters": float(itl.mean()), "max_iters": float(itl.max()), "converged_frac": float((stl == 0).mean()),
-                             "status_counts": {str(k): int((stl == k).sum()) for k in np.unique(stl)},
-                             "roofline": {"bound": "fp64-valu", "kernel": "nmpc_lidar::lidar_solve_kernel", "kernel_ms": kl,
-                                          "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
-                                          "flops_per_iteration": fl_iter_l, "flops_per_launch": fl_iter_l * float(itl.sum()),
-                                          "algorithmic_bytes_per_launch": alg_bytes,
-                                          "hbm_frac_of_algorithmic_bytes": alg_bytes / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "frac_sustained": ach / FP64_SUSTAINED_TFLOPS,
-                                          "note": "flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5); latency-bound: one wavefront per instance, serial recursions over 100 stages"}})
-        ls2 = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
-        v3, ms3, same3 = two_stream_rate([ls, ls2], torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), rl_, 4)
-        out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
-        del ls2
-        # PMC traffic of the LIDAR kernel (profiles/current_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
         try:
-            pdl = profile_dir("lidar", Bl)
-            tjl = json.load(open(os.path.join(ROOT, "profiles", pdl, "hbm_traffic.json")))
-            rll = out["sweep"][-1]["roofline"]
-            if tjl.get("library_src_hash") and ("src=" + tjl["library_src_hash"]) in lib_version and tjl["workload"].get("batch_per_gpu") == Bl:
-                rll["traffic"] = tjl["hbm_bytes_per_iteration"] * float(itl.sum())
-                rll["traffic_GBps"] = rll["traffic"] / (kl * 1e-3) / 1e9
-                rll["traffic_source"] = "profiles/%s@src=%s" % (pdl, tjl["library_src_hash"])
-            else:
-                rll["traffic_source"] = "null: profiles/%s is of another build or batch (src=%s)" % (pdl, tjl.get("library_src_hash"))
-        except (OSError, KeyError, ValueError):
-            pass
-        # CPU baseline of the LIDAR workload: the C oracle (oracle/lidar_oracle.c, OpenMP one instance per thread) on a bounded sample
-        if args.cpu_sample != 0:
-            from oracle import oracle_lib as OL, lidar_ref as LR
-            lc = LR.lidar_v4()          # the checker's own definition of the same literals
-            coresl = OL.max_threads()
-            nl = min(Bl, 4 * coresl)
-            OL.lidar_solve_batch(lc, Pl[:coresl], Wl[:coresl], lbx=lbx, ubx=ubx)
-            t1 = time.perf_counter()
-            refl = OL.lidar_solve_batch(lc, Pl[:nl], Wl[:nl], lbx=lbx, ubx=ubx)
-            t_cpul = time.perf_counter() - t1
-            dwl = np.max(np.abs(rl_["x"][:nl].cpu().numpy() - refl["x"]), axis=1)
-            out["sweep"][-1]["cpu_baseline"] = {"value": nl / t_cpul, "unit": "solves/s", "cores": coresl, "kind": "port",
-                                                "sample": "first %d instances of the same batch, OpenMP one instance per thread, %.2f s; CPU restatement "
-                                                          "(oracle/lidar_oracle.c), not CasADi/IPOPT" % (nl, t_cpul),
-                                                "mean_iters": float(refl["iters"].mean()), "same_point_frac_vs_gpu": float((dwl <= 1e-6).mean())}
-        del ls
-        torch.cuda.empty_cache()
+            lc = nmpc_amd.lidar_v4()
+            Bl = 4096
+            rngl = np.random.Generator(np.random.PCG64(SEED0 + 5))
+            poses, worlds, goals = [], [], []
+            for _ in range(Bl):
+                poses.append([rngl.uniform(0.0, 0.15), rngl.uniform(0.0, 0.15), rngl.uniform(0.4, 1.1)])
+                worlds.append([(float(rngl.uniform(0.8, 2.6)), float(rngl.uniform(0.3, 2.4)), float(rngl.uniform(0.15, 0.3))) for _ in range(3)])
+                goals.append(np.array([3.0, 2.5, 0.0]) + rngl.uniform(-0.3, 0.3, 3))
+            poses = np.array(poses); worlds = np.array(worlds)
+            lbx, ubx = lc.bounds()[:2]
+            ls = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
+            scans = ls.scan_batch(poses, worlds).cpu().numpy()          # the synthetic LaserScan of V4:29-36, on the device (nmpc_lidar_scan_batch)
+            Pl = np.stack([nmpc_amd.lidar_params(lc, poses[b], goals[b], scans[b]) for b in range(Bl)])
+            Wl = np.stack([nmpc_amd.lidar_cold_start(lc, np.concatenate([poses[b], scans[b]])) for b in range(Bl)])
+            dl, kl, rl_ = timed_solves(ls, torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), 2, 1, barrier)
+            itl = rl_["iters"].cpu().numpy(); stl = rl_["status"].cpu().numpy()
+            alg_bytes = (8.0 * (lc.n_p + 2 * lc.n_var) + 16.0) * Bl
+            # Algorithmic flops per interior-point iteration of the LIDAR-state NLP, the same dense-Riccati count as SURVEY.md
+            # 8(d) applied to what the kernel factors: the 3-state / 2-control pose recursion (the R distance states of a stage are eliminated
+            # through their own linearised rows): F_ric = N (7/3 3^3 + 4 3^2 2 + 2 3 2^2 + 2^3/3); folding the distance rows into the pose block
+            # and recovering their steps: F_fold = N R (2 (3 3 + 3) + 2 3); evaluation / assembly: F_asm = N (22 + 14 R)
+            fl_iter_l = lc.N * ((7.0 / 3.0) * 27 + 4 * 9 * 2 + 2 * 3 * 4 + 8.0 / 3.0) + lc.N * lc.R * 30.0 + lc.N * (22.0 + 14.0 * lc.R)
+            ach = fl_iter_l * float(itl.sum()) / (kl * 1e-3) / 1e12
+            out["sweep"].append({"workload": "lidar_v4: 1 robot, 13 states (pose + 10 ray distances), N=100, Nc=50, batch=%d, cold start" % Bl,
+                                 "m": 1, "N": lc.N, "batch": Bl, "value": Bl * 2 / dl, "unit": "solves/s", "ms_per_step": 1e3 * dl / 2,
+                                 "mean_iters": float(itl.mean()), "max_iters": float(itl.max()), "converged_frac": float((stl == 0).mean()),
+                                 "status_counts": {str(k): int((stl == k).sum()) for k in np.unique(stl)},
+                                 "roofline": {"bound": "fp64-valu", "kernel": "nmpc_lidar::lidar_solve_kernel", "kernel_ms": kl,
+                                              "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                                              "flops_per_iteration": fl_iter_l, "flops_per_launch": fl_iter_l * float(itl.sum()),
+                                              "algorithmic_bytes_per_launch": alg_bytes,
+                                              "hbm_frac_of_algorithmic_bytes": alg_bytes / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "frac_sustained": ach / FP64_SUSTAINED_TFLOPS,
+                                              "note": "flops = iters * (F_ric + F_fold + F_asm) of the reduced 3-state recursion (DESIGN.md 4.5); latency-bound: one wavefront per instance, serial recursions over 100 stages"}})
+            ls2 = nmpc_amd.LidarSolver(lc, lbx=lbx, ubx=ubx, max_batch=Bl)
+            v3, ms3, same3 = two_stream_rate([ls, ls2], torch.as_tensor(Pl, device="cuda"), torch.as_tensor(Wl, device="cuda"), rl_, 4)
+            out["sweep"][-1]["two_streams"] = {"solves_per_s": v3, "ms_per_launch": ms3, "same_iterations": same3}
+            del ls2
+            # PMC traffic of the LIDAR kernel (profiles/current_lidar, same stamp rule as the main kernel): bytes per iteration x iterations of this launch
+            try:
+                pdl = profile_dir("lidar", Bl)
+                tjl = json.load(open(os.path.join(ROOT, "profiles", pdl, "hbm_traffic.json")))
+                rll = out["sweep"][-1]["roofline"]
+                if tjl.get("library_src_hash") and ("src=" + tjl["library_src_hash"]) in lib_version and tjl["workload"].get("batch_per_gpu") == Bl:
+                    rll["traffic"] = tjl["hbm_bytes_per_iteration"] * float(itl.sum())
+                    rll["traffic_GBps"] = rll["traffic"] / (kl * 1e-3) / 1e9
+                    rll["traffic_source"] = "profiles/%s@src=%s" % (pdl, tjl["library_src_hash"])
+                else:
+                    rll["traffic_source"] = "null: profiles/%s is of another build or batch (src=%s)" % (pdl, tjl.get("library_src_hash"))
+            except (OSError, KeyError, ValueError):
+                pass
+            # CPU baseline of the LIDAR workload: the C oracle (oracle/lidar_oracle.c, OpenMP one instance per thread) on a bounded sample
+            if args.cpu_sample != 0:
+                from oracle import oracle_lib as OL, lidar_ref as LR
+                lc = LR.lidar_v4()          # the checker's own definition of the same literals
+                coresl = OL.max_threads()
+                nl = min(Bl, 4 * coresl)
+                OL.lidar_solve_batch(lc, Pl[:coresl], Wl[:coresl], lbx=lbx, ubx=ubx)
+                t1 = time.perf_counter()
+                refl = OL.lidar_solve_batch(lc, Pl[:nl], Wl[:nl], lbx=lbx, ubx=ubx)
+                t_cpul = time.perf_counter() - t1
+                dwl = np.max(np.abs(rl_["x"][:nl].cpu().numpy() - refl["x"]), axis=1)
+                out["sweep"][-1]["cpu_baseline"] = {"value": nl / t_cpul, "unit": "solves/s", "cores": coresl, "kind": "port",
+                                                    "sample": "first %d instances of the same batch, OpenMP one instance per thread, %.2f s; CPU restatement "
+                                                              "(oracle/lidar_oracle.c), not CasADi/IPOPT" % (nl, t_cpul),
+                                                    "mean_iters": float(refl["iters"].mean()), "same_point_frac_vs_gpu": float((dwl <= 1e-6).mean())}
+            del ls
+            torch.cuda.empty_cache()
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("sweep: %r" % (e_,))
     # (measured last: the OpenMP team of the oracle keeps the host cores spinning for a while after it returns)
     # CPU baseline: the C oracle on this box's host cores, bounded sample of the same workload
     if world == 1 and args.cpu_sample != 0:
-        from oracle import oracle_lib as O
-        from tests import helpers as Hh
-        ocfg = Hh.to_oracle_cfg(cfg)
-        cores = O.max_threads()
-        n = args.cpu_sample if args.cpu_sample > 0 else min(B, 16 * cores)
-        oc = O.make_config(ocfg, max_iter=args.max_iter)
-        O.solve_batch(oc, P[:cores], W0[:cores])                  # warm the threads / page in
-        t1 = time.perf_counter()
-        ref = O.solve_batch(oc, P[:n], W0[:n])
-        t_cpu = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": n / t_cpu, "unit": "solves/s", "cores": cores, "kind": "port",
-                               "sample": "first %d instances of the same batch, OpenMP one instance per thread, %.2f s; "
-                                         "CPU restatement (oracle/nmpc_oracle.c), not CasADi/IPOPT" % (n, t_cpu),
-                               "mean_iters": float(ref["iters"].mean())}
-        # the GPU results of those instances agree with the oracle (same-basin fraction reported, not asserted here)
-        dw = np.max(np.abs(r["x"][:n].cpu().numpy() - ref["x"]), axis=1)
-        out["cpu_baseline"]["same_basin_frac_vs_gpu"] = float((dw <= 1e-6).mean())
+        try:
+            from oracle import oracle_lib as O
+            from tests import helpers as Hh
+            ocfg = Hh.to_oracle_cfg(cfg)
+            cores = O.max_threads()
+            n = args.cpu_sample if args.cpu_sample > 0 else min(B, 16 * cores)
+            oc = O.make_config(ocfg, max_iter=args.max_iter)
+            O.solve_batch(oc, P[:cores], W0[:cores])                  # warm the threads / page in
+            t1 = time.perf_counter()
+            ref = O.solve_batch(oc, P[:n], W0[:n])
+            t_cpu = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": n / t_cpu, "unit": "solves/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d instances of the same batch, OpenMP one instance per thread, %.2f s; "
+                                             "CPU restatement (oracle/nmpc_oracle.c), not CasADi/IPOPT" % (n, t_cpu),
+                                   "mean_iters": float(ref["iters"].mean())}
+            # the GPU results of those instances agree with the oracle (same-basin fraction reported, not asserted here)
+            dw = np.max(np.abs(r["x"][:n].cpu().numpy() - ref["x"]), axis=1)
+            out["cpu_baseline"]["same_basin_frac_vs_gpu"] = float((dw <= 1e-6).mean())
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("cpu: %r" % (e_,))
     # the extra CPU row of BASELINE.md 3 / SURVEY.md 8(d): nlpsol('ipopt') on the identical NLP built through the CasADi API by the build's own
     # generator (oracle/casadi_probe.py) — only if casadi happens to be importable on this box; the record says which
     if world == 1 and args.cpu_sample != 0:
-        from oracle import casadi_probe as CP
-        from tests import helpers as Hh
-        ok_ca, what_ca = CP.available()
-        if not ok_ca:
-            out["casadi"] = "not importable on this box (%s): no CasADi/IPOPT row, parity stays unpinned" % what_ca
-        else:
-            n_ca = min(B, 8)
-            ref_ca = CP.solve(Hh.to_oracle_cfg(cfg), P[:n_ca], W0[:n_ca])
-            dca = np.max(np.abs(r["x"][:n_ca].cpu().numpy() - ref_ca["x"]), axis=1)
-            out["casadi"] = {"version": what_ca, "value": 1.0 / float(ref_ca["seconds"].mean()), "unit": "solves/s", "cores": 1, "kind": "casadi-ipopt (own generator, C6:345 options)",
-                             "sample": "first %d instances, one thread" % n_ca, "same_point_frac_vs_gpu": float((dca <= 1e-6).mean()), "return_status": sorted(set(ref_ca["return_status"]))}
+        try:
+            from oracle import casadi_probe as CP
+            from tests import helpers as Hh
+            ok_ca, what_ca = CP.available()
+            if not ok_ca:
+                out["casadi"] = "not importable on this box (%s): no CasADi/IPOPT row, parity stays unpinned" % what_ca
+            else:
+                n_ca = min(B, 8)
+                ref_ca = CP.solve(Hh.to_oracle_cfg(cfg), P[:n_ca], W0[:n_ca])
+                dca = np.max(np.abs(r["x"][:n_ca].cpu().numpy() - ref_ca["x"]), axis=1)
+                out["casadi"] = {"version": what_ca, "value": 1.0 / float(ref_ca["seconds"].mean()), "unit": "solves/s", "cores": 1, "kind": "casadi-ipopt (own generator, C6:345 options)",
+                                 "sample": "first %d instances, one thread" % n_ca, "same_point_frac_vs_gpu": float((dca <= 1e-6).mean()), "return_status": sorted(set(ref_ca["return_status"]))}
+        except Exception as e_:      # an extra must never cost the record its headline: note the failure and go on
+            out.setdefault("extras_failed", []).append("cpu: %r" % (e_,))
     # LAST key: a digest of everything above in a few hundred characters — a record that keeps only the tail of this line still holds every
     # sweep entry (solves/s, roofline fraction, traffic), the closed-loop and host-buffer rates, the CPU baseline and the casadi probe
     dg = {"six_B%d" % B: [round(value), round(out["roofline"]["frac"], 4), round(out["roofline"].get("traffic_GBps") or 0)]}
