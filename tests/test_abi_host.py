@@ -499,3 +499,25 @@ def test_bench_workload_is_built_from_the_product_side():
     from tests import helpers as Hh
     for name, oc in (("two", R.cfg_two(20)), ("six", R.cfg_six(20)), ("ten20", R.cfg_ten(20)), ("ten", R.cfg_ten(30))):
         assert Hh.to_oracle_cfg(bench.workload(name)[0]) == oc, name
+
+
+def test_committed_bench_record_and_its_table():
+    """profiles/current/bench.json is a complete line of bench.py (the contract's keys, roofline and cpu_baseline blocks, the digest as the last
+    key) taken from the library whose profiles sit next to it, and tools/design_table.py — the generator of DESIGN.md 7 — still reads it."""
+    import json
+    rec = os.path.join(ROOT, "profiles", "current", "bench.json")
+    d = json.load(open(rec))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert list(d)[-1] == "digest" and d["unit"] == "solves/s" and d["dtype"] == "f64" and d["vs_baseline"] is None and d["n_gpus"] == 1
+    assert d["config"]["workload"].startswith("centralized_six_robots") and d["config"]["batch_per_gpu"] == 4096
+    rl = d["roofline"]
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12 and rl["traffic"] and rl["traffic_source"].startswith("profiles/current@src=")
+    assert rl["traffic_source"].split("src=")[1] in d["library"]          # the traffic figure comes from THIS build's profile
+    tj = json.load(open(os.path.join(ROOT, "profiles", "current", "hbm_traffic.json")))
+    assert tj["library_src_hash"] in d["library"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "extras_failed" not in d
+    assert d["two_streams"]["same_iterations_as_value_run"] is True and d["two_streams"]["solves_per_s"] > d["value"]
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "design_table.py"), rec], text=True)
+    rows = [l for l in out.splitlines() if l.startswith("| ")]
+    assert len(rows) == 1 + 9 and "**headline**" in rows[1] and "LIDAR" in rows[-1], out[:400]      # header + nine shapes (the separator line starts with "|-")
