@@ -508,6 +508,24 @@ def test_composite_closed_loop_soak_has_no_failed_solve(built):
     assert ep.collision_free.all()
 
 
+def test_closed_loop_as_fleets_equals_the_single_fleet(built):
+    """nmpc_amd.simulate_closed_loop_fleets: the same episodes run as three fleets (one handle, one HIP stream, one host thread each) — swarms are
+    independent, so every per-swarm statistic equals the single-fleet run; only the dispatch order inside a launch differs (results do not depend on it)."""
+    import nmpc_amd
+    ocfg = R.cfg_six(20)
+    B = 200
+    P, _ = Hh.batch(ocfg, B, 6)
+    goals = np.stack([P[:, ocfg.nx:], P[::-1, ocfg.nx:]], axis=1)        # two goals per swarm
+    kw = dict(max_steps=30, stop_tol=5e-2, keep_states=True)
+    one = nmpc_amd.simulate_closed_loop(_solver(ocfg, B, max_iter=2000), P[:, : ocfg.nx], goals, **kw)
+    fl = nmpc_amd.simulate_closed_loop_fleets(Hh.to_product_cfg(ocfg, max_iter=2000), P[:, : ocfg.nx], goals, fleets=3, **kw)
+    assert fl.steps == one.steps == 30 and fl.total_solves == one.total_solves == B * 30 and fl.failed_solves == one.failed_solves
+    for k in ("arrived", "arrival_step", "collision_free", "deadlocked"):
+        assert np.array_equal(getattr(fl, k), getattr(one, k)), k
+    assert np.array_equal(fl.states, one.states) and np.array_equal(fl.min_pair_distance, one.min_pair_distance) and np.array_equal(fl.final_error, one.final_error)
+    assert np.allclose(fl.mean_iters_by_step, one.mean_iters_by_step, rtol=0, atol=1e-9)
+
+
 def _preset_names():
     import importlib
     return importlib.import_module("nmpc_amd").script_names()
