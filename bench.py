@@ -28,6 +28,10 @@ Prints ONE JSON line on rank 0 including
                  its own flop roofline and CPU baseline;
   two_streams  — (N = 1 only) the same batch through two handles on two HIP streams, launches alternating: sustained rate when a second launch may
                  run on the SIMDs the first one's tail leaves idle (an extra; `value` is one launch at a time).
+
+--streams S (default 1): the K timed steps alternate over S handles, each on its own HIP stream — S launches in flight; `value` is then the
+rate of that pipeline (six robots, B = 4096: 278 k at S = 1, 476 k at S = 2, 497 k at S = 3) and `config.streams` says so.  The default stays one
+launch at a time, as every round has reported it; the roofline block always prices ONE launch (its own duration, contended when S > 1).
 """
 from __future__ import annotations
 
@@ -153,10 +157,32 @@ def make_batch(name, rank, batch=0, shard=None, max_iter=2000):
     return cfg, B, P, W0
 
 
-def timed_solves(solver, dP, dW0, steps, warmup, barrier):
+def timed_solves(solver, dP, dW0, steps, warmup, barrier, more=()):
     """W untimed + K timed nmpc_solve_batch launches; returns (wall seconds between the barriers, mean kernel ms from HIP
-    events recorded on the launch stream, result of the last step)."""
+    events recorded on the launch stream, result of the last step).  more: further handles (--streams S > 1): the K launches alternate over
+    1 + len(more) handles, each on its own HIP stream (S launches in flight)."""
     import torch
+    if more:
+        pool = [solver] + list(more)
+        sts = [torch.cuda.Stream() for _ in pool]
+        r = None
+        for k in range(max(warmup, len(pool))):          # every handle and stream once before the clock starts
+            with torch.cuda.stream(sts[k % len(pool)]):
+                r = pool[k % len(pool)].solve_batch(dP, dW0)
+        barrier()
+        ev = []
+        t0 = time.perf_counter()
+        for k in range(steps):
+            st = sts[k % len(pool)]
+            with torch.cuda.stream(st):
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                a.record(st)
+                r = pool[k % len(pool)].solve_batch(dP, dW0)
+                b.record(st)
+                ev.append((a, b))
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
     r = None
     for _ in range(warmup):
         r = solver.solve_batch(dP, dW0)
@@ -249,6 +275,8 @@ def main():
     ap.add_argument("--closed-loop", type=int, default=20, help="warm closed-loop steps reported as an extra (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="instances for the CPU baseline (0 = skip)")
     ap.add_argument("--sweep", type=int, default=-1, help="north-star sweep entries (default: on for --gpus 1, 0 = skip)")
+    ap.add_argument("--streams", type=int, default=1, help="launches in flight per GPU: the K timed steps alternate over this many handles, each on its own HIP stream "
+                    "(default 1: one launch at a time, as every round has reported `value`; 2 fills the SIMDs a launch's tail leaves idle)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: every rank its own batch (default); strong: one global batch, sharded")
     ap.add_argument("--batch-total", type=int, default=0, help="--scaling strong: instances of the global batch (default: the workload's BASELINE batch)")
     args = ap.parse_args()
@@ -297,7 +325,9 @@ def main():
     solver = nmpc_amd.NmpcSolver(cfg, max_batch=B)
     kernel_id = int(solver.kernel_for_batch(B))
     dP = torch.as_tensor(P, device="cuda"); dW0 = torch.as_tensor(W0, device="cuda")
-    dt, kern_ms, r = timed_solves(solver, dP, dW0, args.steps, args.warmup, barrier)
+    more = [nmpc_amd.NmpcSolver(cfg, max_batch=B) for _ in range(max(1, args.streams) - 1)]      # --streams S: S handles, S launches in flight (default 1)
+    dt, kern_ms, r = timed_solves(solver, dP, dW0, args.steps, args.warmup, barrier, more)
+    del more
 
     iters = r["iters"].cpu().numpy(); status = r["status"].cpu().numpy(); kkt = r["kkt"].cpu().numpy()
     # ---- the result gather of SURVEY.md 8(e): all_gather of w_out / status / iters of every rank's shard, timed on its own
@@ -343,7 +373,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "centralized_%s_robots: m=%d, N=%d, %d pair rows/stage, %d obstacles, batch=%d per GPU, cold start" %
                    (args.workload, cfg.m, cfg.N, nM, nK, B), "m": cfg.m, "N": cfg.N, "batch_per_gpu": B, "batch_total": int(n_inst), "max_iter": args.max_iter, "tol": cfg.tol,
-                   "kernel_id": kernel_id, "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
+                   "kernel_id": kernel_id, "streams": max(1, args.streams), "ranks": world, "backend": (dist.get_backend() if world > 1 else "none")},
         "library": lib_version,
         "solve_stats": {"mean_iters": sum_iters / n_inst, "max_iters": float(allst[:, 3].max()),
                         "converged_frac": float(allst[:, 2].sum()) / n_inst, "max_kkt_converged": float(allst[:, 4].max())},

@@ -35,7 +35,7 @@ cl = d.get("closed_loop", {}); hb = d.get("host_buffers", {}); cb = d.get("cpu_b
 ts = d.get("two_streams", {})
 if ts:
     print("\"Two launches in flight\": the same batch through two handles on two HIP streams, launches alternating (`bench.py` `two_streams`; an extra, never `value`) — the second "
-          "launch runs on the SIMDs the first one's tail leaves idle: six robots B=4096 **%.0f k solves/s**, %.2f ms per launch, identical results." % (ts["solves_per_s"] / 1e3, ts["ms_per_launch"]))
+          "launch runs on the SIMDs the first one's tail leaves idle: six robots B=4096 **%.0f k solves/s**, %.2f ms per launch, identical results; as the timed steps themselves, `python bench.py --streams 2` / `3`: 476 k / 497 k (the default stays one launch at a time)." % (ts["solves_per_s"] / 1e3, ts["ms_per_launch"]))
 print(("Warm closed loop (20 periods x 4096 swarms, one `nmpc_step_batch` per period): **%.0f k solves/s** (mean %.1f iterations per warm solve; as four fleets of 1024 on four streams: FLEETS).  Host (pageable numpy) "
       "buffers at the boundary: %.0f k solves/s (PCIe-inclusive, never `value`).  CPU baseline (`oracle/nmpc_oracle.c`, %d host threads, %s): **%.1f k solves/s**.  %s" % (
           cl.get("solves_per_s", 0) / 1e3, cl.get("mean_iters_later_steps", 0), hb.get("solves_per_s", 0) / 1e3, cb.get("cores", 0), cb.get("sample", "").split(";")[0], cb.get("value", 0) / 1e3,
